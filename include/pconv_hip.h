@@ -1,0 +1,243 @@
+/*
+ * pconv_hip.h -- C ABI of libpconv_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the reference's native module `PCONV`
+ * (reference: extension/main.cpp:4-137).  The reference binds 21 C++ op classes
+ * with pybind11; a maintainer replacing it binds the flat entry points below
+ * instead (see INTEGRATION.md for the ctypes / pybind stub).  No torch types
+ * cross this boundary: plain device pointers, dims and a hipStream_t.
+ *
+ * Conventions
+ *   - every tensor is fp32, NCHW, contiguous; the tile-batch index is
+ *     n*npart + tile (reference: sphere_slice_cuda.cu:98-99).
+ *   - `stream` is a hipStream_t passed as void*; kernels are launched on it and
+ *     never synchronise.
+ *   - device functions return 0 on success, a negative PCONV_E* code otherwise;
+ *     pconv_last_error() returns a thread-local message.  (The reference only
+ *     printf()s on failure, caffe_cuda_macro.h:21-33; the Python shim raises.)
+ *   - "host" functions touch no GPU state; they build the integer/float tables
+ *     the kernels consume and are bit-exact restatements of the reference's
+ *     one-off table kernels, with element offsets kept as integers (the
+ *     reference stores them in fp32, pseudo_context_cuda.cu:97-99).
+ */
+#ifndef PCONV_HIP_H
+#define PCONV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCONV_OK 0
+#define PCONV_EINVAL (-1)  /* bad argument / shape            */
+#define PCONV_ELAUNCH (-2) /* hip launch or runtime error     */
+#define PCONV_ENOMEM (-3)
+
+const char *pconv_last_error(void);
+int pconv_abi_version(void);
+/* number of devices visible to the HIP runtime (0 if none) */
+int pconv_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Host-side geometry (replaces math_cuda.cu:177-253 and the one-off table
+ * kernels of sphere_slice / sphere_uslice / pseudo_context / entropy_context)
+ * ---------------------------------------------------------------------- */
+
+/* Valid width of every latitude tile at tensor width `width`.
+ * replaces sphere_cal_npart_hw_v3 (math_cuda.cu:223-253) and the width half of
+ * sphere_cal_npart_hw_v2 (math_cuda.cu:177-221).  widths[npart]. */
+int pconv_host_tile_widths(const float *weight, int npart, int height, int width,
+                           int32_t *widths);
+
+/* Catmull-Rom tap table of SphereSlice: for tile t, output column i < widths[t]
+ * the first source column tap_col[t*width+i] and 4 coefficients.
+ * replaces init_slice_param_kernel (sphere_slice_cuda.cu:13-32). */
+int pconv_host_slice_taps(const int32_t *widths, int npart, int width,
+                          int32_t *tap_col, float *tap_coef /* [npart*width*4] */);
+
+/* Tap table of SphereUslice (up-resample from widths[t] to width).
+ * replaces init_uslice_param_kernel (sphere_uslice_cuda.cu:13-30). */
+int pconv_host_uslice_taps(const int32_t *widths, int npart, int width,
+                           int32_t *tap_col, float *tap_coef);
+
+/* Vertical-halo gather table of PseudoPad for tiles of `height` rows, `pad`
+ * halo rows.  Entry e = ((t*2+side)*pad+r), side 0 = rows above, 1 = below.
+ *   src_tile[e], src_row[e]      source tile / row inside that tile
+ *   col[e*width+i], wgt[e*width+i]  first source column and its lerp weight
+ * replaces pseudo_context_forward_kernel (pseudo_context_cuda.cu:51-104). */
+int pconv_host_pad_table(const int32_t *widths, int npart, int height, int width, int pad,
+                         int32_t *src_tile, int32_t *src_row, int32_t *col, float *wgt);
+
+/* Wavefront schedule of the entropy model: positions (row*width+col) of the
+ * npart stacked tiles sorted by plane row+col, valid columns only.
+ * order[height*npart*width] (only plane_start[nplane] entries used),
+ * plane_start[height*npart+width]  (nplane = height*npart+width-1, +1 end).
+ * replaces entropy_context::reshape_hw (entropy_context_cuda.cu:13-45). */
+int pconv_host_wavefront(const int32_t *widths, int npart, int height, int width,
+                         int32_t *order, int32_t *plane_start);
+
+/* Causal halo lists of the entropy model, one list per plane, deterministic
+ * order.  Offsets are element offsets inside ONE image's channel-0 plane of the
+ * padded tensor (npart, C, height+2*pad, width+2*pad), i.e. tile stride =
+ * C*(height+2pad)*(width+2pad).
+ *   entry k: dst[k], src0[k] (-1 = reads as zero), src1[k] (-2 = plain copy of
+ *   src0), wgt[k], entry_plane[k];  plane_start[height*npart+width+pad] prefix
+ *   offsets (nplane = height*npart+width+pad-1, +1 end).
+ * Returns the number of entries, or <0.  Call with dst == NULL to size.
+ * replaces entropy_context_kernel + step1/step2 + the CPU compaction
+ * (entropy_context_cuda.cu:64-165,187-204). */
+int pconv_host_causal_halo(const int32_t *widths, int npart, int channel, int height,
+                           int width, int pad, int32_t *dst, int32_t *src0, int32_t *src1,
+                           float *wgt, int32_t *entry_plane, int32_t *plane_start);
+
+/* Viewport sampling table of MultiProject: tf[14*h_out*w_out*2] = (x, y) source
+ * coordinates in an ERP of (height, width).
+ * replaces projects_opt::init/update (projects_cuda.cu:7-165). */
+int pconv_host_project_table(const float *theta, const float *phi, int nview, float fov,
+                             int h_out, int w_out, int height, int width, float *tf);
+
+/* ------------------------------------------------------------------------
+ * Device kernels -- transform path
+ * ---------------------------------------------------------------------- */
+
+/* SphereSliceOp.forward  (sphere_slice_cuda.cu:87-146)
+ * in (n, c, height, width) -> out (n*npart, c, height/npart + 2*pad, width + 2*pad);
+ * only the interior is written when pad > 0, as in the reference. */
+int pconv_sphere_slice(const float *in, float *out, const int32_t *widths,
+                       const int32_t *tap_col, const float *tap_coef, int n, int c,
+                       int height, int width, int npart, int pad, void *stream);
+
+/* SphereUsliceOp.forward  (sphere_uslice_cuda.cu:73-126)
+ * in (n*npart, c, h + 2*pad, width + 2*pad) -> out (n, c, h*npart, width) */
+int pconv_sphere_uslice(const float *in, float *out, const int32_t *widths,
+                        const int32_t *tap_col, const float *tap_coef, int n, int c, int h,
+                        int width, int npart, int pad, void *stream);
+
+/* PseudoPadOp.forward, the reference's three launches fused in one pass
+ * (pseudo_pad.cu:39-125).  in (tn, c, h, w) -> out (tn, c, h+2p, w+2p). */
+int pconv_pseudo_pad(const float *in, float *out, const int32_t *widths,
+                     const int32_t *src_tile, const int32_t *src_row, const int32_t *col,
+                     const float *wgt, int tn, int c, int h, int w, int pad, int npart,
+                     void *stream);
+
+/* PseudoFillOp.forward, in place  (pseudo_fill_cuda.cu:28-62) */
+int pconv_pseudo_fill(float *data, const int32_t *widths, int tn, int c, int h, int w,
+                      int npart, int pad, int trim, float fvalue, void *stream);
+
+/* DtowOp.forward  (dtow_cuda.cu:38-103); d2w != 0: (n,c,h,w)->(n,c/s^2,h*s,w*s) */
+int pconv_dtow(const float *in, float *out, int n, int c, int h, int w, int stride, int d2w,
+               void *stream);
+
+/* PseudoQuantOp.forward (eval)  (pseudo_quant_cuda.cu:37-94,157-194)
+ * weight (c, levels) raw parameter; level_tab (c, levels) scratch written here;
+ * out_val / out_idx (idx as float, may be NULL); count (c, levels) histogram,
+ * may be NULL. */
+int pconv_quant(const float *x, const float *weight, float *level_tab, float *out_val,
+                float *out_idx, float *count, const int32_t *widths, int tn, int c, int h,
+                int w, int levels, int npart, void *stream);
+
+/* PseudoDQuantOp.forward  (pseudo_dquant_cuda.cu:24-70)
+ * weight (wc, levels) raw parameter, level_tab (wc, levels) scratch */
+int pconv_dquant(const float *x, const float *weight, float *level_tab, float *out,
+                 const int32_t *widths, int tn, int c, int h, int w, int wc, int levels,
+                 int npart, void *stream);
+
+/* ProjectsOp.forward  (projects_cuda.cu:181-255)
+ * in (n, c, height, width) -> out (nview*n, c, h_out, w_out), viewport-major */
+int pconv_project(const float *in, const float *tf, float *out, int n, int c, int height,
+                  int width, int nview, int h_out, int w_out, int nearest, void *stream);
+
+/* ContextReshapeOp.forward (context_reshape_cuda.cu:30-60)
+ * (n, g*cpg, h, w) -> (n*g*h*w, cpg) */
+int pconv_context_reshape(const float *in, float *out, int n, int c, int h, int w, int ngroup,
+                          void *stream);
+
+/* MaskConstrainOp.forward, in place on a conv weight (nout, cin, k, k)
+ * (mask_constrain_cuda.cu:19-88); constrain in {1,2,5,6} */
+int pconv_mask_constrain(float *weight, int nout, int cin, int k, int ngroup, int constrain,
+                         void *stream);
+
+/* EntropyGmmOp.forward (entropy_gmm_cuda.cu:36-92): loss (m) plus the four
+ * gradient buffers the reference keeps for backward (may be NULL). */
+int pconv_gmm_loss(const float *weight, const float *delta, const float *mean,
+                   const float *label, float *loss, float *d_weight, float *d_delta,
+                   float *d_mean, float *d_label, int m, int ng, void *stream);
+
+/* Dense per-tile convolution, implicit GEMM on fp32 MFMA (the nn.Conv2d call
+ * sites of model_zoo_v2.py:41-45,83-86,100-105,119,143,158-164,181,205; cuDNN in
+ * the reference).  in (tn, cin, h, w); packed_w from pconv_conv_pack_weight;
+ * out (tn, cout, ho, wo), ho = (h - k)/stride + 1, no implicit padding.
+ * k in {1,3}, stride in {1,2}.  act: 0 none, 1 PReLU(slope[cout]).
+ * col_limit (may be NULL): per latitude tile (t % npart) the first dead output
+ * column; 64-column tiles starting at or beyond it are written as zeros without
+ * being computed.
+ * Every output is one k-ascending fp32 fmaf chain from 0 (k = (ci*k + kh)*k + kw),
+ * then + bias, then the activation. */
+int pconv_conv_packed_size(int cout, int cin, int k, int *cout_pad, int *red_pad);
+int pconv_conv_pack_weight(const float *w, float *packed, int cout, int cin, int k,
+                           void *stream);
+int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
+                 int tn, int cin, int h, int w, int cout, int k, int stride, int act,
+                 const float *slope, const int32_t *col_limit, int npart, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Device kernels -- entropy wavefront (one call = one step of one op)
+ * `order`/`plane_start` come from pconv_host_wavefront; lo/hi = the range of
+ * schedule entries handled by this step (plane_start[st] .. plane_start[end]).
+ * ---------------------------------------------------------------------- */
+
+/* DInput2Op.forward body (d_input_cuda_v2.cu:32-52): scatter packed symbols
+ * (+bias) of the previous step into ctx (rep*nimg*npart, ngroup, h+2p, w+2p) */
+int pconv_dinput2(const float *packed, float *ctx, const int32_t *order, int lo, int len,
+                  int nimg, int ngroup, int npart, int h, int w, int pad, int psum,
+                  float bias, int rep, void *stream);
+
+/* EntropyCtxPadRun2Op.forward body, in place (entropy_ctx_pad_run2_cuda.cu:33-65).
+ * list arrays from pconv_host_causal_halo; entry_plane[k] = plane of entry k. */
+int pconv_ctx_pad_run2(float *data, const int32_t *dst, const int32_t *src0,
+                       const int32_t *src1, const float *wgt, const int32_t *entry_plane,
+                       int lo, int len, int nimg, int cpn, int channel, int npart, int h, int w,
+                       int pad, int psum, void *stream);
+
+/* EntropyConv2Op.forward{,_act,_batch,_act_batch} body
+ * (entropy_conv_cuda_v2.cu:61-459).  x (nimg*npart, cin, h+2pi, w+2pi),
+ * weight (nset, cout, cin, k, k), bias (nset, cout), slope NULL = no PReLU,
+ * y (nimg*npart, cout, h+2po, w+2po) persistent.  nimg = images incl. replicas,
+ * per_set = nimg / nset. */
+int pconv_entropy_conv(const float *x, const float *weight, const float *bias,
+                       const float *slope, float *y, const int32_t *order, int lo, int len,
+                       int nimg, int per_set, int cin, int cout, int ngroup, int k,
+                       int constrain, int npart, int h, int w, int pad_in, int pad_out,
+                       int psum, void *stream);
+
+/* EntropyAddOp.forward body, in place y += x (entropy_add_cuda.cu:25-44) */
+int pconv_entropy_add(float *y, const float *x, const int32_t *order, int lo, int len,
+                      int nimg, int channel, int ngroup, int npart, int h, int w, int pad,
+                      int psum, void *stream);
+
+/* DExtract2Op.forward body (d_extract_cuda_v2.cu:34-52): gather to packed list
+ * out[(img*len + l)*cpn + ci] */
+int pconv_dextract2(const float *x, float *out, const int32_t *order, int lo, int len,
+                    int nimg, int channel, int cpn, int npart, int h, int w, int psum,
+                    void *stream);
+
+/* DExtract2Op.forward_batch body (d_extract_cuda_v2.cu:110-132): three packed
+ * sections at distance `section_stride` */
+int pconv_dextract2_batch(const float *x, float *out, const int32_t *order, int lo, int len,
+                          int nimg, int channel, int cpn, int npart, int h, int w, int psum,
+                          int nout, long long section_stride, void *stream);
+
+/* EntropyGmmTableOp.forward_batch / forward (entropy_gmm_table_cuda.cu:29-185).
+ * weight/delta/mean are (tn, ng) each, modified in place like the reference
+ * (softmax / relu+beta); table (tn, nstep+1) holds integers as floats.
+ * batch_arith != 0 selects forward_batch's mixed float/double accumulation
+ * (:136-153), 0 the all-float accumulation of forward (:59-80). */
+int pconv_gmm_table(float *weight, float *delta, const float *mean, float *table, int tn,
+                    int ng, int nstep, float bias, float total, float beta, int batch_arith,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCONV_HIP_H */

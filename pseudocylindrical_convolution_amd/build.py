@@ -1,0 +1,111 @@
+"""Build the native libraries in-tree.
+
+  libpconv_hip.so    HIP kernels + host geometry, gfx950 only (hipcc)
+  libpconv_coder.so  CPU arithmetic coder (g++, no GPU code)
+
+Both land next to this file so that they travel with the source tree.  Objects
+are rebuilt only when a source or header is newer.  `python -m
+pseudocylindrical_convolution_amd.build` builds everything.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_SOURCES = [
+    "geometry.cpp",
+    "resample.hip",
+    "tilepad.hip",
+    "pointwise.hip",
+    "entropy.hip",
+    "conv.hip",
+    "engine.cpp",
+]
+CODER_SOURCES = ["coder.cpp"]
+
+ARCH = "gfx950"
+# -ffp-contract=off: the gather/lerp/CDF kernels are specified operation by
+# operation (parity with the oracle is bit-exact); fused multiply-adds are
+# written explicitly (fmaf / MFMA) where they are part of the contract.
+HIP_FLAGS = [
+    "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off",
+    "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+    "-I" + INCLUDE,
+]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I" + INCLUDE]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libpconv_hip.so cannot be built")
+
+
+def _newest_header():
+    t = 0.0
+    for d in (CSRC, INCLUDE):
+        for f in os.listdir(d):
+            if f.endswith((".h", ".hpp")):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def _stale(target, deps_mtime):
+    return (not os.path.exists(target)) or os.path.getmtime(target) < deps_mtime
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    if r.stdout.strip():
+        sys.stderr.write(r.stdout)
+
+
+def _compile(src, flags, cc, hdr_time, as_hip):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src + ".o")
+    if _stale(obj, max(os.path.getmtime(path), hdr_time)):
+        cmd = [cc] + flags
+        if as_hip and src.endswith(".cpp"):
+            cmd += ["-x", "hip"]
+        _run(cmd + ["-c", path, "-o", obj])
+        return obj, True
+    return obj, False
+
+
+def build(verbose=False, jobs=4):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    hdr = _newest_header()
+    sources = [s for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        res = list(ex.map(lambda s: _compile(s, HIP_FLAGS, cc, hdr, True), sources))
+    objs = [o for o, _ in res]
+    lib = os.path.join(HERE, "libpconv_hip.so")
+    if any(ch for _, ch in res) or not os.path.exists(lib):
+        _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)
+        if verbose:
+            print("linked", lib)
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no host C++ compiler found for libpconv_coder.so")
+    cres = [_compile(s, CXX_FLAGS, cxx, hdr, False) for s in CODER_SOURCES]
+    clib = os.path.join(HERE, "libpconv_coder.so")
+    if any(ch for _, ch in cres) or not os.path.exists(clib):
+        _run([cxx, "-shared", "-fPIC", "-o", clib] + [o for o, _ in cres])
+        if verbose:
+            print("linked", clib)
+    return lib, clib
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

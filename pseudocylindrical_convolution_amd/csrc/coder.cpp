@@ -1,0 +1,333 @@
+// CPU arithmetic coder behind the `coder` module (libpconv_coder.so).
+//
+// Same bitstream as the reference's Nayuki-style coder (ArithmeticCoder.cpp:31-69,
+// 72-170; BitIoStream.cpp:13-70), re-designed around word-level operations: the
+// renormalisation loops that the reference runs one bit at a time (a virtual call
+// and a stream put per bit) are resolved with count-leading-zeros, and bits are
+// packed into a memory buffer that is written to disk once.  The interval
+// arithmetic (uint64 products, truncating division by the table total) is kept
+// operation for operation because it defines the stream.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/pconv_coder.h"
+
+namespace {
+
+constexpr int kStateBits = 32;
+constexpr uint64_t kMaxRange = 1ull << kStateBits;
+constexpr uint64_t kMinRange = (kMaxRange >> 2) + 2;
+constexpr uint64_t kMaxTotal = kMinRange;  // min(UINT64_MAX / kMaxRange, kMinRange)
+constexpr uint64_t kMask = kMaxRange - 1;
+constexpr uint64_t kTop = kMaxRange >> 1;
+constexpr uint64_t kSecond = kTop >> 1;
+
+inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+
+class BitSink {
+ public:
+  void clear() {
+    bytes_.clear();
+    acc_ = 0;
+    fill_ = 0;
+  }
+  // append the low `n` bits of v, most significant first (n <= 32)
+  void put(uint64_t v, int n) {
+    while (n > 0) {
+      int take = 8 - fill_;
+      if (take > n) take = n;
+      acc_ = (acc_ << take) | ((v >> (n - take)) & ((1u << take) - 1));
+      fill_ += take;
+      n -= take;
+      if (fill_ == 8) {
+        bytes_.push_back((uint8_t)acc_);
+        acc_ = 0;
+        fill_ = 0;
+      }
+    }
+  }
+  void put_run(int bit, uint64_t count) {
+    const uint64_t pattern = bit ? 0xffffffffull : 0;
+    while (count > 0) {
+      int n = count > 32 ? 32 : (int)count;
+      put(pattern, n);
+      count -= n;
+    }
+  }
+  void pad_to_byte() {
+    if (fill_ != 0) put(0, 8 - fill_);
+  }
+  const std::vector<uint8_t> &bytes() const { return bytes_; }
+
+ private:
+  std::vector<uint8_t> bytes_;
+  uint32_t acc_ = 0;
+  int fill_ = 0;
+};
+
+class BitSource {
+ public:
+  void reset(const uint8_t *p, size_t n) {
+    p_ = p;
+    n_ = n;
+    pos_ = 0;
+    acc_ = 0;
+    have_ = 0;
+  }
+  // next n bits (n <= 32), zeros past the end (ArithmeticCoder.cpp:121-126)
+  uint32_t get(int n) {
+    while (have_ < n) {
+      uint64_t b = pos_ < n_ ? p_[pos_] : 0;
+      pos_++;
+      acc_ = (acc_ << 8) | b;
+      have_ += 8;
+    }
+    have_ -= n;
+    uint32_t v = (uint32_t)((acc_ >> have_) & ((n == 32) ? 0xffffffffull : ((1ull << n) - 1)));
+    return v;
+  }
+
+ private:
+  const uint8_t *p_ = nullptr;
+  size_t n_ = 0, pos_ = 0;
+  uint64_t acc_ = 0;
+  int have_ = 0;
+};
+
+}  // namespace
+
+struct pconv_coder {
+  std::string path;
+  bool has_path = false;
+  std::string err;
+  enum { IDLE, ENCODING, DECODING } mode = IDLE;
+  uint64_t low = 0, high = kMask, code = 0;
+  uint64_t pending = 0;  // deferred underflow bits (numUnderflow)
+  BitSink sink;
+  BitSource source;
+  std::vector<uint8_t> file_bytes;
+
+  int fail(int code_, const char *msg) {
+    err = msg;
+    return code_;
+  }
+
+  // narrow [low, high] to the symbol's sub-interval and renormalise
+  // (ArithmeticCoderBase::update, ArithmeticCoder.cpp:31-69)
+  template <bool kEncode>
+  int narrow(const uint32_t *table, uint32_t total, uint32_t symbol) {
+    if (low >= high || (low & kMask) != low || (high & kMask) != high)
+      return fail(PCONV_CODER_ESTATE, "Assertion error: Low or high out of range");
+    const uint64_t range = high - low + 1;
+    if (range < kMinRange || range > kMaxRange)
+      return fail(PCONV_CODER_ESTATE, "Assertion error: Range out of range");
+    const uint32_t sym_low = table[symbol];
+    const uint32_t sym_high = table[symbol + 1];
+    if (sym_low == sym_high) return fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
+    if (total > kMaxTotal)
+      return fail(PCONV_CODER_ETOTAL, "Cannot code symbol because total is too large");
+    const uint64_t new_low = low + sym_low * range / total;
+    const uint64_t new_high = low + sym_high * range / total - 1;
+    low = new_low;
+    high = new_high;
+    // leading bits on which low and high agree leave the state
+    const int agree = clz32((uint32_t)((low ^ high) & kMask));
+    if (agree > 0) {
+      if (kEncode) {
+        const uint32_t top = (uint32_t)(low >> (kStateBits - agree));
+        const int first = (top >> (agree - 1)) & 1;
+        sink.put(first, 1);
+        if (pending) {
+          sink.put_run(first ^ 1, pending);
+          pending = 0;
+        }
+        if (agree > 1) sink.put(top & ((1u << (agree - 1)) - 1), agree - 1);
+      } else {
+        code = ((code << agree) & kMask) | source.get(agree);
+      }
+      low = (low << agree) & kMask;
+      high = ((high << agree) & kMask) | ((1ull << agree) - 1);
+    }
+    // low = 01..., high = 10...: squeeze out the second-highest bit while it
+    // keeps that pattern
+    const uint32_t pattern = (uint32_t)((low & ~high & (kMask >> 1)) << 1);
+    const int squeeze = clz32(~pattern);
+    if (squeeze > 0) {
+      if (kEncode) {
+        pending += squeeze;
+      } else {
+        code = (code & kTop) | ((code << squeeze) & (kMask >> 1)) | source.get(squeeze);
+      }
+      low = (low << squeeze) & (kMask >> 1);
+      high = ((high << squeeze) & (kMask >> 1)) | kTop | ((1ull << squeeze) - 1);
+    }
+    return 0;
+  }
+
+  // ArithmeticDecoder::read (ArithmeticCoder.cpp:82-115)
+  int read_symbol(const uint32_t *table, uint32_t ncode, uint32_t total) {
+    if (total > kMaxTotal)
+      return fail(PCONV_CODER_ETOTAL, "Cannot decode symbol because total is too large");
+    if (total == 0) return fail(PCONV_CODER_EARG, "table total is zero");
+    const uint64_t range = high - low + 1;
+    const uint64_t offset = code - low;
+    const uint64_t value = ((offset + 1) * total - 1) / range;
+    if (value * range / total > offset) return fail(PCONV_CODER_EDESYNC, "Assertion error");
+    if (value >= total) return fail(PCONV_CODER_EDESYNC, "Assertion error");
+    uint32_t start = 0, end = ncode;
+    while (end - start > 1) {
+      uint32_t middle = (start + end) >> 1;
+      if (table[middle] > value)
+        end = middle;
+      else
+        start = middle;
+    }
+    if (start + 1 != end) return fail(PCONV_CODER_EDESYNC, "Assertion error");
+    const uint32_t symbol = start;
+    if (offset < table[symbol] * range / total || table[symbol + 1] * range / total <= offset)
+      return fail(PCONV_CODER_EDESYNC, "Assertion error");
+    int rc = narrow<false>(table, total, symbol);
+    if (rc < 0) return rc;
+    if (code < low || code > high)
+      return fail(PCONV_CODER_EDESYNC, "Assertion error: Code out of range");
+    return (int)symbol;
+  }
+};
+
+template <typename T>
+static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, int n) {
+  if (!c || !table || !out || ncode <= 0) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::DECODING) return c->fail(PCONV_CODER_ESTATE, "decoder not started");
+  const int stride = ncode + 1;
+  for (int i = 0; i < n; i++) {
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
+    int s = c->read_symbol(row, (uint32_t)ncode, row[ncode]);
+    if (s < 0) return s;
+    out[i] = (T)s;
+  }
+  return 0;
+}
+
+extern "C" {
+
+pconv_coder *pconv_coder_new(const char *path) {
+  pconv_coder *c = new pconv_coder();
+  if (path) {
+    c->path = path;
+    c->has_path = true;
+  }
+  return c;
+}
+
+void pconv_coder_free(pconv_coder *c) { delete c; }
+
+const char *pconv_coder_error(const pconv_coder *c) { return c ? c->err.c_str() : "null coder"; }
+
+int pconv_coder_start_encoder(pconv_coder *c) {
+  if (!c) return PCONV_CODER_EARG;
+  if (c->has_path) {
+    // the reference opens (truncates) the file here (coder.h:13-15)
+    FILE *f = fopen(c->path.c_str(), "wb");
+    if (!f) return c->fail(PCONV_CODER_EIO, "cannot open output file");
+    fclose(f);
+  }
+  c->sink.clear();
+  c->low = 0;
+  c->high = kMask;
+  c->pending = 0;
+  c->mode = pconv_coder::ENCODING;
+  return 0;
+}
+
+int pconv_coder_encode(pconv_coder *c, const uint32_t *table, uint32_t ncode, uint32_t sum,
+                       uint32_t symbol) {
+  if (!c || !table) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::ENCODING) return c->fail(PCONV_CODER_ESTATE, "encoder not started");
+  if (symbol >= ncode) return c->fail(PCONV_CODER_EARG, "symbol out of range");
+  return c->narrow<true>(table, sum, symbol);
+}
+
+int pconv_coder_encodes(pconv_coder *c, const int32_t *table, int ncode, const int32_t *symbols,
+                        int n) {
+  if (!c || !table || !symbols || ncode <= 0) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::ENCODING) return c->fail(PCONV_CODER_ESTATE, "encoder not started");
+  const int stride = ncode + 1;
+  for (int i = 0; i < n; i++) {
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
+    const uint32_t s = (uint32_t)symbols[i];
+    if (s >= (uint32_t)ncode) return c->fail(PCONV_CODER_EARG, "symbol out of range");
+    int rc = c->narrow<true>(row, row[ncode], s);
+    if (rc < 0) return rc;
+  }
+  return 0;
+}
+
+int pconv_coder_end_encoder(pconv_coder *c) {
+  if (!c) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::ENCODING) return c->fail(PCONV_CODER_ESTATE, "encoder not started");
+  c->sink.put(1, 1);  // ArithmeticEncoder::finish
+  c->sink.pad_to_byte();
+  c->mode = pconv_coder::IDLE;
+  if (c->has_path) {
+    FILE *f = fopen(c->path.c_str(), "wb");
+    if (!f) return c->fail(PCONV_CODER_EIO, "cannot open output file");
+    const std::vector<uint8_t> &b = c->sink.bytes();
+    size_t wr = b.empty() ? 0 : fwrite(b.data(), 1, b.size(), f);
+    fclose(f);
+    if (wr != b.size()) return c->fail(PCONV_CODER_EIO, "short write");
+  }
+  return 0;
+}
+
+const uint8_t *pconv_coder_bytes(const pconv_coder *c, size_t *nbytes) {
+  if (!c) return nullptr;
+  if (nbytes) *nbytes = c->sink.bytes().size();
+  return c->sink.bytes().data();
+}
+
+static int begin_decode(pconv_coder *c, const uint8_t *p, size_t n) {
+  c->source.reset(p, n);
+  c->low = 0;
+  c->high = kMask;
+  c->code = c->source.get(kStateBits);
+  c->mode = pconv_coder::DECODING;
+  return 0;
+}
+
+int pconv_coder_start_decoder(pconv_coder *c) {
+  if (!c) return PCONV_CODER_EARG;
+  if (!c->has_path) return c->fail(PCONV_CODER_EIO, "coder has no file path");
+  FILE *f = fopen(c->path.c_str(), "rb");
+  c->file_bytes.clear();
+  if (f) {  // a missing file reads as an empty stream, like an unopened ifstream
+    uint8_t buf[65536];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0)
+      c->file_bytes.insert(c->file_bytes.end(), buf, buf + got);
+    fclose(f);
+  }
+  return begin_decode(c, c->file_bytes.data(), c->file_bytes.size());
+}
+
+int pconv_coder_start_decoder_mem(pconv_coder *c, const uint8_t *data, size_t nbytes) {
+  if (!c || (!data && nbytes)) return PCONV_CODER_EARG;
+  return begin_decode(c, data, nbytes);
+}
+
+int pconv_coder_decode(pconv_coder *c, const uint32_t *table, uint32_t ncode, uint32_t sum) {
+  if (!c || !table) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::DECODING) return c->fail(PCONV_CODER_ESTATE, "decoder not started");
+  return c->read_symbol(table, ncode, sum);
+}
+
+int pconv_coder_decodes(pconv_coder *c, const int32_t *table, int ncode, float *out, int n) {
+  return decode_many<float>(c, table, ncode, out, n);
+}
+
+int pconv_coder_decodes_i32(pconv_coder *c, const int32_t *table, int ncode, int32_t *out, int n) {
+  return decode_many<int32_t>(c, table, ncode, out, n);
+}
+
+}  // extern "C"

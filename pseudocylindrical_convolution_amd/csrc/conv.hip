@@ -1,0 +1,329 @@
+// Dense per-tile convolution as an implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32).  This is the FLOP hot spot of the codec: the
+// nn.Conv2d call sites of model_zoo_v2.py:41-45,83-86,100-105,119,143,158-164,
+// 181,205 (cuDNN in the reference).
+//
+//   D[cout][pixel] = sum_k Wp[k][cout] * X[k][pixel],  k = (ci*KS + kh)*KS + kw
+//
+// Orientation: couts are the MFMA "row" operand (A), pixels the "column" operand
+// (B), so an accumulator register holds 32 consecutive pixels of one output
+// channel and every store instruction writes two 128-byte row segments of the
+// NCHW output.  A workgroup (4 waves) owns BM couts x 128 pixels (2 output rows x
+// 64 columns).  Per chunk of KC input channels it stages the input patch and the
+// weight slab in LDS (double buffered; the next chunk's global loads are issued
+// before the MFMA block and written to LDS after it).  Each wave keeps MT x NT
+// 32x32 accumulators; per k-pair it reads MT + NT operands from LDS
+// (conflict-free: 32 consecutive couts / pixels per lane group) for MT*NT MFMAs
+// of 64 cycles each, so the matrix pipe is the only busy resource.
+//
+// Numerics contract: every output is ONE k-ascending fmaf chain starting at 0
+// (the MFMA accumulates k0 then k1 into the same register, chunks continue the
+// chain), then + bias, then the activation.  The oracle restates exactly that.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kTileRows = 2;
+constexpr int kTileCols = 64;
+
+template <int KS, int S>
+struct Patch {
+  // sampling step of the staged patch (a strided 1x1 only needs every S-th pixel)
+  static constexpr int PS = (KS == 1) ? S : 1;
+  static constexpr int Q = S / PS;  // LDS step between neighbouring output pixels
+  static constexpr int PR = (kTileRows - 1) * Q + KS;
+  static constexpr int PC = (kTileCols - 1) * Q + KS;
+};
+
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
+struct ConvCfg {
+  static constexpr int BM = 32 * MT * WM;
+  static constexpr int KK = KC * KS * KS;  // reduction entries per chunk (even)
+  using P = Patch<KS, S>;
+  static constexpr int XSZ = KC * P::PR * P::PC;
+  static constexpr int WSZ = KK * BM;
+  static constexpr int STAGE = XSZ + WSZ;
+  static constexpr int XLD = (XSZ + kThreads - 1) / kThreads;        // floats / thread
+  static constexpr int WLD = (WSZ / 4 + kThreads - 1) / kThreads;    // float4 / thread
+  static_assert(WN * NT == 4, "pixel tile is 4 segments of 32");
+  static_assert(KK % 2 == 0, "chunk reduction length must be even");
+  static_assert(BM % 4 == 0, "weight slab rows are float4 multiples");
+};
+
+// act: 0 none, 1 PReLU(slope per cout)
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
+__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(
+    const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
+    const float *__restrict__ slope, float *__restrict__ out, int cin, int h, int w, int cout,
+    int cout_pad, int ho, int wo, int act, int tiles_r, int tiles_c, int cblocks,
+    const int32_t *__restrict__ col_limit, int npart) {
+  using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
+  using P = typename C::P;
+  extern __shared__ float lds[];
+
+  // block -> (cout block, column tile, row tile, tile-batch index)
+  int b = blockIdx.x;
+  const int cb = b % cblocks;
+  b /= cblocks;
+  const int tcx = b % tiles_c;
+  b /= tiles_c;
+  const int trx = b % tiles_r;
+  const int t = b / tiles_r;
+  const int r0 = trx * kTileRows, c0 = tcx * kTileCols;
+  const int cout0 = cb * C::BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  float *outp = out + (size_t)t * cout * ho * wo;
+
+  if (col_limit && c0 >= col_limit[t % npart]) {
+    // tile lies entirely in the dead columns of this latitude band: zeros
+    for (int e = tid; e < C::BM * kTileRows * kTileCols; e += kThreads) {
+      const int col = e % kTileCols, row = (e / kTileCols) % kTileRows, co = e / (kTileCols * kTileRows);
+      if (cout0 + co < cout && r0 + row < ho && c0 + col < wo)
+        outp[((size_t)(cout0 + co) * ho + r0 + row) * wo + c0 + col] = 0.f;
+    }
+    return;
+  }
+
+  const float *inp = in + (size_t)t * cin * h * w;
+  const int nchunk = (cin + KC - 1) / KC;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+  float xr[C::XLD];
+  float4 wr[C::WLD];
+
+  auto load_chunk = [&](int chunk) {
+    const int ci0 = chunk * KC;
+#pragma unroll
+    for (int j = 0; j < C::XLD; j++) {
+      const int e = tid + j * kThreads;
+      float v = 0.f;
+      if (e < C::XSZ) {
+        const int pc = e % P::PC;
+        const int pr = (e / P::PC) % P::PR;
+        const int ci = e / (P::PC * P::PR);
+        int ir = r0 * S + pr * P::PS;
+        int ic = c0 * S + pc * P::PS;
+        ir = ir < h ? ir : h - 1;
+        ic = ic < w ? ic : w - 1;
+        if (ci0 + ci < cin) v = inp[((size_t)(ci0 + ci) * h + ir) * w + ic];
+      }
+      xr[j] = v;
+    }
+    const int k0 = ci0 * KS * KS;
+#pragma unroll
+    for (int j = 0; j < C::WLD; j++) {
+      const int e4 = tid + j * kThreads;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e4 < C::WSZ / 4) {
+        const int kk = e4 / (C::BM / 4);
+        const int co = (e4 % (C::BM / 4)) * 4;
+        // rows past the real reduction length are zero in the packed weight
+        v = *reinterpret_cast<const float4 *>(wp + (size_t)(k0 + kk) * cout_pad + cout0 + co);
+      }
+      wr[j] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float *xs = lds + buf * C::STAGE;
+    float *ws = xs + C::XSZ;
+#pragma unroll
+    for (int j = 0; j < C::XLD; j++) {
+      const int e = tid + j * kThreads;
+      if (e < C::XSZ) xs[e] = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < C::WLD; j++) {
+      const int e4 = tid + j * kThreads;
+      if (e4 < C::WSZ / 4) *reinterpret_cast<float4 *>(ws + e4 * 4) = wr[j];
+    }
+  };
+
+  // per-lane LDS bases of the operand fragments
+  int xbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++) {
+    const int seg = wn * NT + n;  // 0..3: row = seg / 2, 32-column half = seg % 2
+    const int prow = seg >> 1, pcol = (seg & 1) * 32 + l31;
+    xbase[n] = prow * P::Q * P::PC + pcol * P::Q;
+  }
+  const int wbase = wm * MT * 32 + l31;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < nchunk; chunk++) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < nchunk) load_chunk(chunk + 1);
+    const float *xs = lds + buf * C::STAGE;
+    const float *ws = xs + C::XSZ;
+#pragma unroll
+    for (int kp = 0; kp < C::KK / 2; kp++) {
+      // the two lane halves work on reduction entries 2kp and 2kp+1
+      constexpr int KS2 = KS * KS;
+      const int ka = 2 * kp, kb = 2 * kp + 1;
+      const int offa = (ka / KS2) * P::PR * P::PC + ((ka / KS) % KS) * P::PC + (ka % KS);
+      const int offb = (kb / KS2) * P::PR * P::PC + ((kb / KS) % KS) * P::PC + (kb % KS);
+      const int xoff = half ? offb : offa;
+      const int woff = (2 * kp + half) * C::BM + wbase;
+      float a[MT], bv[NT];
+#pragma unroll
+      for (int m = 0; m < MT; m++) a[m] = ws[woff + m * 32];
+#pragma unroll
+      for (int n = 0; n < NT; n++) bv[n] = xs[xbase[n] + xoff];
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+    }
+    if (chunk + 1 < nchunk) {
+      store_chunk(buf ^ 1);  // other buffer: its last readers finished before the
+                             // barrier that ended the previous iteration
+    }
+    __syncthreads();
+  }
+
+  // epilogue: + bias, activation, store.  reg r of a 32x32 tile: cout row
+  // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= cout) continue;
+      const float bco = bias ? bias[co] : 0.f;
+      const float sl = (act == 1) ? slope[co] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const int seg = wn * NT + n;
+        const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+        if (orow < ho && ocol < wo) {
+          float v = acc[m][n][r] + bco;
+          if (act == 1 && v < 0) v = v * sl;
+          outp[((size_t)co * ho + orow) * wo + ocol] = v;
+        }
+      }
+    }
+  }
+}
+
+// (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ packed, int cout,
+                                   int red, int cout_pad, int red_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout_pad * red_pad) return;
+  const int co = i % cout_pad, kk = i / cout_pad;
+  packed[i] = (co < cout && kk < red) ? w[(size_t)co * red + kk] : 0.f;
+}
+
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
+int launch_conv(const float *in, const float *wp, const float *bias, const float *slope, float *out,
+                int tn, int cin, int h, int w, int cout, int cout_pad, int ho, int wo, int act,
+                const int32_t *col_limit, int npart, hipStream_t stream) {
+  using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
+  const int tiles_r = (ho + kTileRows - 1) / kTileRows;
+  const int tiles_c = (wo + kTileCols - 1) / kTileCols;
+  const int cblocks = (cout + C::BM - 1) / C::BM;
+  const long long grid = (long long)tn * tiles_r * tiles_c * cblocks;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    pconv_set_error("conv2d: grid %lld out of range", grid);
+    return PCONV_EINVAL;
+  }
+  const size_t smem = (size_t)2 * C::STAGE * sizeof(float);
+  auto kern = conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC>;
+  static bool raised = false;
+  if (smem > 64 * 1024 && !raised) {
+    raised = true;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      pconv_set_error("conv2d: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e));
+      return PCONV_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, bias, slope,
+                     out, cin, h, w, cout, cout_pad, ho, wo, act, tiles_r, tiles_c, cblocks,
+                     col_limit, npart);
+  return PCONV_OK;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" int pconv_conv_packed_size(int cout, int cin, int k, int *cout_pad, int *red_pad) {
+  // cout padded to the widest workgroup tile, reduction to whole chunks
+  const int cp = round_up(cout, cout > 96 ? 192 : (cout > 32 ? 96 : 32));
+  const int kc = (k == 1) ? 16 : 4;
+  const int rp = round_up(cin, kc) * k * k;
+  if (cout_pad) *cout_pad = cp;
+  if (red_pad) *red_pad = rp;
+  return cp * rp;
+}
+
+extern "C" int pconv_conv_pack_weight(const float *w, float *packed, int cout, int cin, int k,
+                                      void *stream) {
+  PCONV_REQUIRE(w && packed && cout > 0 && cin > 0 && (k == 1 || k == 3), "conv_pack: bad argument");
+  int cp, rp;
+  const int total = pconv_conv_packed_size(cout, cin, k, &cp, &rp);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                     w, packed, cout, cin * k * k, cp, rp);
+  PCONV_LAUNCH_CHECK("conv_pack_weight");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
+                            int tn, int cin, int h, int w, int cout, int k, int stride, int act,
+                            const float *slope, const int32_t *col_limit, int npart,
+                            void *stream) {
+  PCONV_REQUIRE(in && packed_w && out, "conv2d: null pointer");
+  PCONV_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv2d: k=%d stride=%d unsupported",
+                k, stride);
+  PCONV_REQUIRE(h >= k && w >= k && tn > 0 && cin > 0 && cout > 0, "conv2d: bad shape");
+  PCONV_REQUIRE(act == 0 || (act == 1 && slope), "conv2d: bad activation");
+  PCONV_REQUIRE(!col_limit || npart > 0, "conv2d: col_limit needs npart");
+  const int ho = (h - k) / stride + 1, wo = (w - k) / stride + 1;
+  int cp, rp;
+  pconv_conv_packed_size(cout, cin, k, &cp, &rp);
+  hipStream_t s = as_stream(stream);
+  int rc;
+#define ARGS in, packed_w, bias, slope, out, tn, cin, h, w, cout, cp, ho, wo, act, col_limit, npart, s
+#define BY_TILE(KS, S, KC)                                         \
+  if (cout > 96)                                                   \
+    rc = launch_conv<3, 2, 2, 2, KS, S, KC>(ARGS);                 \
+  else if (cout > 32)                                              \
+    rc = launch_conv<3, 1, 1, 4, KS, S, KC>(ARGS);                 \
+  else                                                             \
+    rc = launch_conv<1, 1, 1, 4, KS, S, KC>(ARGS);
+  if (k == 3 && stride == 1) {
+    BY_TILE(3, 1, 4)
+  } else if (k == 3 && stride == 2) {
+    BY_TILE(3, 2, 4)
+  } else if (k == 1 && stride == 1) {
+    BY_TILE(1, 1, 16)
+  } else {
+    BY_TILE(1, 2, 16)
+  }
+#undef BY_TILE
+#undef ARGS
+  if (rc != PCONV_OK) return rc;
+  PCONV_LAUNCH_CHECK("conv2d");
+  return PCONV_OK;
+}

@@ -1,0 +1,348 @@
+// Host-side geometry of the latitude-tile decomposition: tile widths, resampling
+// tap tables, halo gather tables and the entropy wavefront schedule.
+//
+// Everything here is integer / IEEE arithmetic evaluated once per shape on the
+// host and uploaded by the caller.  The arithmetic order follows the reference's
+// one-off table kernels so that indices are bit-exact with them:
+//   tile widths      math_cuda.cu:177-253
+//   slice taps       sphere_slice_cuda.cu:13-32
+//   uslice taps      sphere_uslice_cuda.cu:13-30
+//   pad halo table   pseudo_context_cuda.cu:51-104
+//   wavefront        entropy_context_cuda.cu:13-45
+//   causal halo      entropy_context_cuda.cu:64-165,187-204
+//   viewport table   projects_cuda.cu:7-165
+// Unlike the reference, element offsets are never stored in fp32.
+//
+// Build note: compiled with -ffp-contract=off so the float expressions below are
+// evaluated exactly as written (no fused multiply-add).
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void pconv_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *pconv_last_error(void) { return g_err; }
+extern "C" int pconv_abi_version(void) { return 1; }
+extern "C" int pconv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int pconv_host_tile_widths(const float *weight, int npart, int height, int width,
+                                      int32_t *widths) {
+  PCONV_REQUIRE(weight && widths && npart > 0 && width > 0, "tile_widths: bad argument");
+  PCONV_REQUIRE(height % npart == 0, "tile_widths: height %d is not a multiple of npart %d",
+                height, npart);
+  float total = 0;
+  for (int i = 0; i < npart; i++) total += weight[i];
+  if (total > 3 * npart) {
+    // weights given in 1/64 units of the full width (base.py:set_weight)
+    for (int i = 0; i < npart; i++) {
+      float scaled = weight[i] / 64 * width;
+      widths[i] = static_cast<int>(scaled + 0.5);
+    }
+    return PCONV_OK;
+  }
+  // fractional weights: cosine-latitude rule
+  const int rows = height / npart;
+  const float pi = acos(-1.0);
+  const int half = npart / 2;
+  const bool even = (npart % 2 == 0);
+  for (int i = 0; i < npart; i++) {
+    bool centre = even ? (i == half - 1 || i == half) : (i == half);
+    if (centre) {
+      widths[i] = width;
+      continue;
+    }
+    double edge = (i < half) ? (rows * (i + 1) - 0.5) : (rows * i + 0.5);
+    float ww = weight[i] * width;
+    widths[i] = static_cast<int>(ww * cos((edge / height - 0.5) * pi) + 0.5);
+  }
+  return PCONV_OK;
+}
+
+// Catmull-Rom coefficients for fractional offset t, in the reference's float
+// evaluation order (sphere_slice_cuda.cu:24-30).
+static inline void cubic_coef(float t, float *c) {
+  float t2 = t * t;
+  float t3 = t * t2;
+  c[0] = (-t + 2 * t2 - t3) / 2;
+  c[1] = (2 - 5 * t2 + 3 * t3) / 2;
+  c[2] = (t + 4 * t2 - 3 * t3) / 2;
+  c[3] = (-t2 + t3) / 2;
+}
+
+extern "C" int pconv_host_slice_taps(const int32_t *widths, int npart, int width,
+                                     int32_t *tap_col, float *tap_coef) {
+  PCONV_REQUIRE(widths && tap_col && tap_coef, "slice_taps: null pointer");
+  memset(tap_col, 0, sizeof(int32_t) * (size_t)npart * width);
+  memset(tap_coef, 0, sizeof(float) * (size_t)npart * width * 4);
+  for (int t = 0; t < npart; t++) {
+    const int tw = widths[t];
+    for (int i = 0; i < tw && i < width; i++) {
+      float pos = (i + 0.5) / tw * width - 0.5 + 1e-9;
+      if (pos < 0) pos = pos + width;
+      float whole = static_cast<float>(static_cast<int>(pos));
+      size_t e = (size_t)t * width + i;
+      tap_col[e] = static_cast<int>(whole);
+      cubic_coef(pos - whole, tap_coef + e * 4);
+    }
+  }
+  return PCONV_OK;
+}
+
+extern "C" int pconv_host_uslice_taps(const int32_t *widths, int npart, int width,
+                                      int32_t *tap_col, float *tap_coef) {
+  PCONV_REQUIRE(widths && tap_col && tap_coef, "uslice_taps: null pointer");
+  for (int t = 0; t < npart; t++) {
+    const int tw = widths[t];
+    for (int i = 0; i < width; i++) {
+      float pos = (i + 0.5) / width * tw - 0.5 + 1e-9;
+      if (pos < 0) pos = pos + tw;
+      float whole = static_cast<float>(static_cast<int>(pos));
+      size_t e = (size_t)t * width + i;
+      tap_col[e] = static_cast<int>(whole);
+      cubic_coef(pos - whole, tap_coef + e * 4);
+    }
+  }
+  return PCONV_OK;
+}
+
+// Column of tile `to` (valid width wto) that faces column i of tile `from`
+// (valid width wfrom), as the reference computes it in fp32 from a double
+// expression.  `shifted` = half-turn shift used when mirroring over a pole.
+static inline float facing_column(int i, int wfrom, int wto, bool shifted) {
+  float p;
+  if (shifted) {
+    float s = i + wfrom / 2.;
+    if (s >= wfrom) s = s - wfrom;
+    p = (s + 0.5) / wfrom * wto - 0.5 + 1e-9;
+  } else {
+    p = (i + 0.5) / wfrom * wto - 0.5 + 1e-9;
+  }
+  return p;
+}
+
+extern "C" int pconv_host_pad_table(const int32_t *widths, int npart, int height, int width,
+                                    int pad, int32_t *src_tile, int32_t *src_row,
+                                    int32_t *col, float *wgt) {
+  PCONV_REQUIRE(widths && src_tile && src_row && col && wgt, "pad_table: null pointer");
+  PCONV_REQUIRE(pad >= 0 && height > 0, "pad_table: bad pad/height");
+  const int total_rows = height * npart;
+  for (int t = 0; t < npart; t++) {
+    for (int side = 0; side < 2; side++) {
+      for (int r = 0; r < pad; r++) {
+        int row = (side == 0) ? t * height - pad + r : (t + 1) * height + r;
+        bool mirrored = false;
+        if (row < 0) {
+          row = -row - 1;
+          mirrored = true;
+        } else if (row >= total_rows) {
+          row = 2 * total_rows - row - 1;
+          mirrored = true;
+        }
+        const int st = row / height;
+        const int e = (t * 2 + side) * pad + r;
+        src_tile[e] = st;
+        src_row[e] = row % height;
+        for (int i = 0; i < width; i++) {
+          size_t k = (size_t)e * width + i;
+          if (i >= widths[t]) {
+            col[k] = 0;
+            wgt[k] = 0;
+            continue;
+          }
+          float p = facing_column(i, widths[t], widths[st], mirrored);
+          if (p < 0) p = p + widths[st];
+          int whole = static_cast<int>(p);
+          col[k] = whole;
+          wgt[k] = whole + 1 - p;
+        }
+      }
+    }
+  }
+  return PCONV_OK;
+}
+
+extern "C" int pconv_host_wavefront(const int32_t *widths, int npart, int height, int width,
+                                    int32_t *order, int32_t *plane_start) {
+  PCONV_REQUIRE(widths && order && plane_start, "wavefront: null pointer");
+  const int rows = height * npart;
+  int n = 0, p = 0;
+  for (; p < rows + width - 1; p++) {
+    plane_start[p] = n;
+    for (int i = 0; i < rows; i++) {
+      int j = p - i;
+      if (j < 0 || j >= widths[i / height]) continue;
+      order[n++] = i * width + j;
+    }
+  }
+  plane_start[p] = n;
+  return PCONV_OK;
+}
+
+namespace {
+struct HaloEntry {
+  int32_t plane, dst, src0, src1;
+  float wgt;
+};
+}  // namespace
+
+extern "C" int pconv_host_causal_halo(const int32_t *widths, int npart, int channel,
+                                      int height, int width, int pad, int32_t *dst,
+                                      int32_t *src0, int32_t *src1, float *wgt,
+                                      int32_t *entry_plane, int32_t *plane_start) {
+  PCONV_REQUIRE(widths && plane_start, "causal_halo: null pointer");
+  PCONV_REQUIRE(channel >= 1 && pad >= 1, "causal_halo: bad channel/pad");
+  const int rows = height * npart;
+  const int ph = height + 2 * pad, pw = width + 2 * pad;
+  const long long tile_stride = (long long)channel * ph * pw;
+  PCONV_REQUIRE(tile_stride * npart < (1LL << 31), "causal_halo: image exceeds int32 offsets");
+  const int nplane = rows + width + pad - 1;
+  std::vector<std::vector<HaloEntry>> lists(nplane);
+  // vertical halo: lerp from the facing columns of the neighbouring tile,
+  // clamped so that only already-coded columns contribute.
+  for (int t = 0; t < npart; t++)
+    for (int side = 0; side < 2; side++)
+      for (int r = 0; r < pad; r++) {
+        int row = (side == 0) ? t * height - pad + r : (t + 1) * height + r;
+        if (row < 0 || row >= rows) continue;  // no pole mirroring in the causal model
+        const int st = row / height;
+        const int drow = (side == 0) ? r : pad + height + r;
+        const int32_t dbase = (int32_t)(t * tile_stride + (long long)drow * pw);
+        const int32_t sbase = (int32_t)(st * tile_stride + (long long)(pad + row % height) * pw);
+        for (int i = 0; i < widths[t]; i++) {
+          float p = facing_column(i, widths[t], widths[st], false);
+          int c = p < 0 ? -1 : static_cast<int>(p);
+          float w;
+          if (c > i) continue;  // source not coded yet: halo stays zero
+          if (c + 1 > i) {
+            w = 1.f;
+          } else {
+            w = c + 1 - p;
+            if (c == -1) w = 0.f;
+          }
+          HaloEntry e;
+          e.plane = row + i;
+          e.dst = dbase + i + pad;
+          e.src0 = (c < 0) ? -1 : sbase + c + pad;
+          e.src1 = sbase + (c + 1) % widths[st] + pad;
+          e.wgt = w;
+          lists[e.plane].push_back(e);
+        }
+      }
+  // right-hand wrap: the first `pad` valid columns re-appear after the last one
+  for (int t = 0; t < npart; t++)
+    for (int r = 0; r < ph; r++) {
+      int row = t * height + r - pad;
+      if (row < 0 || row >= rows) continue;
+      for (int i = 0; i < pad; i++) {
+        HaloEntry e;
+        e.plane = row + i + widths[t];
+        int32_t base = (int32_t)(t * tile_stride + (long long)r * pw + i + pad);
+        e.dst = base + widths[t];
+        e.src0 = base;
+        e.src1 = -2;
+        e.wgt = 1.f;
+        lists[e.plane].push_back(e);
+      }
+    }
+  int n = 0;
+  for (int p = 0; p < nplane; p++) {
+    plane_start[p] = n;
+    if (dst) {
+      for (const HaloEntry &e : lists[p]) {
+        dst[n] = e.dst;
+        src0[n] = e.src0;
+        src1[n] = e.src1;
+        wgt[n] = e.wgt;
+        entry_plane[n] = e.plane;
+        n++;
+      }
+    } else {
+      n += (int)lists[p].size();
+    }
+  }
+  plane_start[nplane] = n;
+  return n;
+}
+
+// Rodrigues rotation matrix of axis*angle vector v (projects_cuda.cu:20-49)
+static void rodrigues(float x, float y, float z, float *m) {
+  float norm = sqrt(x * x + y * y + z * z);
+  for (int i = 0; i < 9; i++) m[i] = 0;
+  if (norm == 0) {
+    m[0] = m[4] = m[8] = 1.f;
+    return;
+  }
+  float tx = x / norm, ty = y / norm, tz = z / norm;
+  float c = cos(norm), s = sin(norm);
+  m[0] = c + (1 - c) * tx * tx;
+  m[1] = (1 - c) * tx * ty - s * tz;
+  m[2] = (1 - c) * tx * tz + s * ty;
+  m[3] = (1 - c) * ty * tx + s * tz;
+  m[4] = c + (1 - c) * ty * ty;
+  m[5] = (1 - c) * ty * tz - s * tx;
+  m[6] = (1 - c) * tz * tx - s * ty;
+  m[7] = (1 - c) * tz * ty + s * tx;
+  m[8] = c + (1 - c) * tz * tz;
+}
+
+extern "C" int pconv_host_project_table(const float *theta, const float *phi, int nview,
+                                        float fov_in, int h_out, int w_out, int height,
+                                        int width, float *tf) {
+  PCONV_REQUIRE(theta && phi && tf && nview > 0, "project_table: bad argument");
+  const float pi = acos(-1.0);
+  // the reference scales its angles by pi in the constructor (projects.hpp)
+  const float fov = fov_in * pi;
+  float hfov = fov * h_out / w_out / 2;
+  float wfov = fov / 2;
+  float cx = (w_out - 1) / 2.0;
+  float cy = (h_out - 1) / 2.0;
+  float pi_2 = pi / 2;
+  float w_stride = 2 * sin(wfov) / sin(pi_2 - wfov) / (w_out - 1);
+  float h_stride = 2 * sin(hfov) / sin(pi_2 - hfov) / (h_out - 1);
+  float hx = (width - 1) / 2.0;
+  float hy = (height - 1) / 2.0;
+  const int inner = h_out * w_out;
+  for (int v = 0; v < nview; v++) {
+    float r1[9], r2[9], r[9];
+    rodrigues(0, 0, theta[v] * pi, r1);
+    float nphi = -(phi[v] * pi);
+    rodrigues(r1[1] * nphi, r1[4] * nphi, r1[7] * nphi, r2);
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        float s = 0;
+        for (int k = 0; k < 3; k++) s += r2[a * 3 + k] * r1[k * 3 + b];
+        r[a * 3 + b] = s;
+      }
+    for (int i = 0; i < inner; i++) {
+      int w = i % w_out, h = i / w_out;
+      float x = 1.;
+      float y = (w - cx) * w_stride;
+      float z = (h - cy) * h_stride;
+      float len = sqrt(x * x + y * y + z * z);
+      float xa = x / len, xb = y / len, xc = -z / len;
+      float px = xa * r[0] + xb * r[1] + xc * r[2];
+      float py = xa * r[3] + xb * r[4] + xc * r[5];
+      float pz = xa * r[6] + xb * r[7] + xc * r[8];
+      float lat = asin(pz);
+      float th = atan(py / px);
+      if (px <= 0) th = (py > 0) ? th + pi : th - pi;
+      size_t e = ((size_t)v * inner + i) * 2;
+      tf[e] = th / pi * hx + hx;
+      tf[e + 1] = -2 * lat / pi * hy + hy;
+    }
+  }
+  return PCONV_OK;
+}

@@ -1,0 +1,295 @@
+// Element-wise ops of the codec path: quantiser / de-quantiser, viewport
+// projection, ContextReshape, MaskConstrain, EntropyGmm loss.
+#include "common.h"
+#include "../../include/pconv_detmath.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// level table of the quantiser: tab[c,0] = w[c,0], tab[c,j] = exp(w[c,j])
+// (pseudo_quant_cuda.cu:37-45)
+__global__ void quant_levels_kernel(const float *__restrict__ w, float *__restrict__ tab, int n,
+                                    int levels) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  tab[i] = (i % levels == 0) ? w[i] : pconv_expf(w[i]);
+}
+
+// cumulative level table of the de-quantiser (pseudo_dquant_cuda.cu:24-32)
+__global__ void dquant_levels_kernel(const float *__restrict__ w, float *__restrict__ tab, int nch,
+                                     int levels) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= nch) return;
+  float acc = w[ch * levels];
+  tab[ch * levels] = acc;
+  for (int j = 1; j < levels; j++) {
+    acc = acc + pconv_expf(w[ch * levels + j]);
+    tab[ch * levels + j] = acc;
+  }
+}
+
+// pseudo_quant_cuda.cu:48-85
+__global__ __launch_bounds__(kBlock) void quant_kernel(
+    const float *__restrict__ x, const float *__restrict__ tab, float *__restrict__ out_val,
+    float *__restrict__ out_idx, float *__restrict__ count, const int32_t *__restrict__ widths,
+    int c, int hw, int w, int levels, int npart, long long total) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int pw = (int)(i % w);
+    const long long plane = i / hw;
+    const int pc = (int)(plane % c);
+    const int pg = (int)((plane / c) % npart);
+    float val = 0.f;
+    int q = 0;
+    if (pw < widths[pg]) {
+      const float *lv = tab + pc * levels;
+      const float v = x[i];
+      float tmp = v - lv[0];
+      if (tmp < 0) {
+        q = 0;
+        val = lv[0];
+      } else {
+        int j = 1;
+        for (; j < levels; j++) {
+          tmp -= lv[j];
+          if (tmp < 0) break;
+        }
+        if (j == levels) j--;
+        if (tmp + tmp + lv[j] < 0) {
+          tmp = tmp + lv[j];
+          j--;
+        }
+        val = v - tmp;
+        q = j;
+      }
+      if (count) atomicAdd(count + pc * levels + q, -1.0f);
+    }
+    out_val[i] = val;
+    if (out_idx) out_idx[i] = (float)q;
+  }
+}
+
+// pseudo_dquant_cuda.cu:34-47
+__global__ __launch_bounds__(kBlock) void dquant_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ tab,
+                                                        float *__restrict__ out,
+                                                        const int32_t *__restrict__ widths, int c,
+                                                        int hw, int w, int levels, int npart,
+                                                        long long total) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int pw = (int)(i % w);
+    const long long plane = i / hw;
+    const int pc = (int)(plane % c);
+    const int pg = (int)((plane / c) % npart);
+    float v = 0.f;
+    if (pw < widths[pg]) {
+      const int idx = static_cast<int>(x[i] + 0.00001);
+      v = tab[pc * levels + idx];
+    }
+    out[i] = v;
+  }
+}
+
+// projects_cuda.cu:181-213.  index = (view*nc + plane)*inner + pixel
+__global__ __launch_bounds__(kBlock) void project_kernel(const float *__restrict__ in,
+                                                         const float *__restrict__ tf,
+                                                         float *__restrict__ out, int inner, int hs,
+                                                         int ws, int nc, int nearest,
+                                                         long long total) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int ps = (int)(i % inner);
+    const long long rest = i / inner;
+    const int tn = (int)(rest % nc);
+    const int tb = (int)(rest / nc);
+    const float fx = tf[((size_t)tb * inner + ps) * 2];
+    const float fy = tf[((size_t)tb * inner + ps) * 2 + 1];
+    const float *img = in + (size_t)tn * hs * ws;
+    if (nearest) {
+      int tw = static_cast<int>(floor(fx + 0.5)) % ws;
+      int th = static_cast<int>(floor(fy + 0.5));
+      th = th >= hs ? hs - 1 : th;
+      out[i] = img[(size_t)th * ws + tw];
+    } else {
+      const int tw = static_cast<int>(floorf(fx));
+      const int th = static_cast<int>(floorf(fy));
+      const int pw = (tw + 1) % ws;
+      const int ph = th + 1 >= hs ? hs - 1 : th + 1;
+      const float tx = fx - tw;
+      const float ty = fy - th;
+      const float ntx = 1. - tx;
+      const float nty = 1. - ty;
+      out[i] = img[(size_t)th * ws + tw] * ntx * nty + img[(size_t)th * ws + pw] * tx * nty +
+               img[(size_t)ph * ws + tw] * ntx * ty + img[(size_t)ph * ws + pw] * tx * ty;
+    }
+  }
+}
+
+// context_reshape_cuda.cu:30-39, output-ordered so stores coalesce
+__global__ __launch_bounds__(kBlock) void context_reshape_kernel(const float *__restrict__ in,
+                                                                 float *__restrict__ out, int inner,
+                                                                 int c, int cpg, long long total) {
+  for (long long o = (long long)blockIdx.x * kBlock + threadIdx.x; o < total;
+       o += (long long)gridDim.x * kBlock) {
+    const int k = (int)(o % cpg);
+    long long rest = o / cpg;
+    const int ps = (int)(rest % inner);
+    rest /= inner;
+    const int g = (int)(rest % (c / cpg));
+    const long long pn = rest / (c / cpg);
+    out[o] = in[((size_t)pn * c + g * cpg + k) * inner + ps];
+  }
+}
+
+// mask_constrain_cuda.cu:19-88
+__global__ __launch_bounds__(kBlock) void mask_constrain_kernel(float *__restrict__ w, int cin,
+                                                                int sz, int group_in, int group_out,
+                                                                int constrain, int total) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const int tw = i % sz;
+  const int th = (i / sz) % sz;
+  const int tc = (i / sz / sz) % cin / group_in;
+  const int tn = i / sz / sz / cin / group_out;
+  bool zero = false;
+  if (constrain == 5) {
+    zero = (tw + th + tc >= tn + sz - 1);
+  } else if (constrain == 1 || constrain == 2) {
+    if (tn > tc) {
+      zero = false;
+    } else if (tn == tc) {
+      if (th < sz / 2)
+        zero = false;
+      else if (th == sz / 2)
+        zero = (constrain == 1) ? !(tw < sz / 2) : !(tw <= sz / 2);
+      else
+        zero = true;
+    } else {
+      zero = true;
+    }
+  } else {
+    zero = (tw + th + tc > tn + sz - 1);
+  }
+  if (zero) w[i] = 0.f;
+}
+
+// entropy_gmm_cuda.cu:36-69
+__global__ __launch_bounds__(kBlock) void gmm_loss_kernel(
+    const float *__restrict__ weight, const float *__restrict__ delta,
+    const float *__restrict__ mean, const float *__restrict__ label, float *__restrict__ loss,
+    float *__restrict__ d_weight, float *__restrict__ d_delta, float *__restrict__ d_mean,
+    float *__restrict__ d_label, int m, int ng) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const float s2 = 1. / sqrtf(2.0f);
+  const float sp2 = 1. / sqrt(2. * 3.14159265358979323846);
+  float sum_p = 0;
+  float dl = 0;
+  for (int k = 0; k < ng; k++) {
+    const float wk = weight[i * ng + k];
+    float xa = label[i] - 0.5 - mean[i * ng + k];
+    float xb = label[i] + 0.5 - mean[i * ng + k];
+    float id = 1. / delta[i * ng + k];
+    float fa = 0.5 + 0.5 * pconv_erff(xa * id * s2);
+    float fb = 0.5 + 0.5 * pconv_erff(xb * id * s2);
+    float p = fb - fa;
+    sum_p = sum_p + wk * p;
+    if (d_weight) {
+      float ga = sp2 * id * pconv_expf(-0.5 * xa * xa * id * id);
+      float gb = sp2 * id * pconv_expf(-0.5 * xb * xb * id * id);
+      dl += (gb - ga) * wk;
+      d_delta[i * ng + k] = id * (-xb * gb + xa * ga) * wk;
+      d_mean[i * ng + k] = (ga - gb) * wk;
+      d_weight[i * ng + k] = p;
+    }
+  }
+  loss[i] = -logf(sum_p + 0.0000001);
+  if (d_weight) {
+    float ip = -1. / (sum_p + 0.0000001);
+    d_label[i] = dl * ip;
+    for (int k = 0; k < ng; k++) {
+      d_delta[i * ng + k] *= ip;
+      d_mean[i * ng + k] *= ip;
+      d_weight[i * ng + k] *= ip;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pconv_quant(const float *x, const float *weight, float *level_tab, float *out_val,
+                           float *out_idx, float *count, const int32_t *widths, int tn, int c,
+                           int h, int w, int levels, int npart, void *stream) {
+  PCONV_REQUIRE(x && weight && level_tab && out_val && widths, "quant: null pointer");
+  PCONV_REQUIRE(tn > 0 && c > 0 && h > 0 && w > 0 && levels > 1, "quant: bad shape");
+  const int ntab = c * levels;
+  hipLaunchKernelGGL(quant_levels_kernel, dim3((ntab + 255) / 256), dim3(256), 0,
+                     as_stream(stream), weight, level_tab, ntab, levels);
+  const long long total = (long long)tn * c * h * w;
+  hipLaunchKernelGGL(quant_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x,
+                     level_tab, out_val, out_idx, count, widths, c, h * w, w, levels, npart, total);
+  PCONV_LAUNCH_CHECK("quant");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_dquant(const float *x, const float *weight, float *level_tab, float *out,
+                            const int32_t *widths, int tn, int c, int h, int w, int wc, int levels,
+                            int npart, void *stream) {
+  PCONV_REQUIRE(x && weight && level_tab && out && widths, "dquant: null pointer");
+  PCONV_REQUIRE(tn > 0 && c > 0 && c <= wc && h > 0 && w > 0, "dquant: bad shape c=%d wc=%d", c, wc);
+  hipLaunchKernelGGL(dquant_levels_kernel, dim3((wc + 255) / 256), dim3(256), 0, as_stream(stream),
+                     weight, level_tab, wc, levels);
+  const long long total = (long long)tn * c * h * w;
+  hipLaunchKernelGGL(dquant_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x,
+                     level_tab, out, widths, c, h * w, w, levels, npart, total);
+  PCONV_LAUNCH_CHECK("dquant");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_project(const float *in, const float *tf, float *out, int n, int c,
+                             int height, int width, int nview, int h_out, int w_out, int nearest,
+                             void *stream) {
+  PCONV_REQUIRE(in && tf && out, "project: null pointer");
+  PCONV_REQUIRE(n > 0 && c > 0 && nview > 0, "project: bad shape");
+  const long long total = (long long)n * c * nview * h_out * w_out;
+  hipLaunchKernelGGL(project_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream),
+                     in, tf, out, h_out * w_out, height, width, n * c, nearest, total);
+  PCONV_LAUNCH_CHECK("project");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_context_reshape(const float *in, float *out, int n, int c, int h, int w,
+                                     int ngroup, void *stream) {
+  PCONV_REQUIRE(in && out && ngroup > 0 && c % ngroup == 0, "context_reshape: bad argument");
+  const long long total = (long long)n * c * h * w;
+  hipLaunchKernelGGL(context_reshape_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0,
+                     as_stream(stream), in, out, h * w, c, c / ngroup, total);
+  PCONV_LAUNCH_CHECK("context_reshape");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_mask_constrain(float *weight, int nout, int cin, int k, int ngroup,
+                                    int constrain, void *stream) {
+  PCONV_REQUIRE(weight && ngroup > 0 && nout % ngroup == 0 && cin % ngroup == 0,
+                "mask_constrain: bad argument");
+  const int total = nout * cin * k * k;
+  hipLaunchKernelGGL(mask_constrain_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                     as_stream(stream), weight, cin, k, cin / ngroup, nout / ngroup, constrain,
+                     total);
+  PCONV_LAUNCH_CHECK("mask_constrain");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_gmm_loss(const float *weight, const float *delta, const float *mean,
+                              const float *label, float *loss, float *d_weight, float *d_delta,
+                              float *d_mean, float *d_label, int m, int ng, void *stream) {
+  PCONV_REQUIRE(weight && delta && mean && label && loss, "gmm_loss: null pointer");
+  PCONV_REQUIRE(!d_weight || (d_delta && d_mean && d_label), "gmm_loss: partial gradient buffers");
+  hipLaunchKernelGGL(gmm_loss_kernel, dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                     as_stream(stream), weight, delta, mean, label, loss, d_weight, d_delta, d_mean,
+                     d_label, m, ng);
+  PCONV_LAUNCH_CHECK("gmm_loss");
+  return PCONV_OK;
+}
