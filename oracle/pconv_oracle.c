@@ -1,0 +1,1088 @@
+/*
+ * pconv_oracle.c -- TEST INFRASTRUCTURE, NOT PART OF THE PRODUCT.
+ *
+ * CPU restatement of the reference's forward kernels for the codec hot path
+ * (SURVEY.md section 8a).  Every function keeps the reference kernel's own
+ * formulation -- a flat `index` over `nthreads`, decoded with the same / and %
+ * chain -- and cites the file:line it follows under /root/reference/extension.
+ * The only intended deviation: element offsets that the reference stores in
+ * fp32 tables (pseudo_context_cuda.cu:97-99, entropy_context_cuda.cu:136-145)
+ * are kept as 64-bit integers (hard part 3).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  Parity status: the reference publishes no vectors for these
+ * kernels and its CUDA build cannot run here, so this restatement is pinned by
+ * the invariants in tests/test_oracle_properties.py only ("parity unpinned" by
+ * reference data).  The arithmetic coder IS pinned against the
+ * compiled reference (oracle/_ref).
+ *
+ * Compile: gcc -O2 -std=c99 -ffp-contract=off (no fused multiply-add unless
+ * written as fmaf).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pconv_detmath.h"
+
+typedef int64_t i64;
+
+/* erf / exp used by the CDF and quantiser tables: 0 = libm (what the reference's
+ * CUDA build would call, up to its own rounding), 1 = the published
+ * deterministic polynomials the product uses (include/pconv_detmath.h). */
+static int g_detmath = 0;
+void orc_set_detmath(int on) { g_detmath = on; }
+static float o_erff(float x) { return g_detmath ? pconv_erff(x) : erff(x); }
+static float o_expf(float x) { return g_detmath ? pconv_expf(x) : expf(x); }
+
+/* ---- math_cuda.cu:177-253 ------------------------------------------------ */
+/* sphere_cal_npart_hw_v2: tidx[0..npart) row ends, tidx[npart..2npart) widths,
+ * hinv[0..height) tile of a row, hinv[height..2height) row inside the tile */
+int orc_cal_npart_hw_v2(int height, int width, int npart, const float *weight, int *tidx,
+                        int *hinv) {
+  if (height % npart != 0) return -1;
+  int heights_per_part = height / npart;
+  for (int i = 0; i < npart; i++) tidx[i] = heights_per_part * (i + 1);
+  float total = 0;
+  for (int i = 0; i < npart; i++) total += weight[i];
+  if (total < 3 * npart) {
+    float pi = acos(-1.0);
+    if (npart % 2 == 0) {
+      for (int i = 0; i < npart / 2 - 1; i++)
+        tidx[i + npart] = (int)(weight[i] * width * cos(((tidx[i] - 0.5) / height - 0.5) * pi) + 0.5);
+      tidx[npart / 2 - 1 + npart] = width;
+      tidx[npart / 2 + npart] = width;
+      for (int i = npart / 2 + 1; i < npart; i++)
+        tidx[i + npart] = (int)(weight[i] * width * cos(((tidx[i - 1] + 0.5) / height - 0.5) * pi) + 0.5);
+    } else {
+      for (int i = 0; i < npart / 2; i++)
+        tidx[i + npart] = (int)(weight[i] * width * cos(((tidx[i] - 0.5) / height - 0.5) * pi) + 0.5);
+      tidx[npart / 2 + npart] = width;
+      for (int i = npart / 2 + 1; i < npart; i++)
+        tidx[i + npart] = (int)(weight[i] * width * cos(((tidx[i - 1] + 0.5) / height - 0.5) * pi) + 0.5);
+    }
+  } else {
+    for (int i = 0; i < npart; i++) tidx[i + npart] = (int)(weight[i] / 64 * width + 0.5);
+  }
+  if (hinv) {
+    for (int i = 0, j = 0; i < npart; i++) {
+      for (int k = j; k < tidx[i]; k++) {
+        hinv[k] = i;
+        hinv[k + height] = k - j;
+      }
+      j = tidx[i];
+    }
+  }
+  return tidx[npart / 2] - tidx[npart / 2 - 1];
+}
+
+/* sphere_cal_npart_hw_v3: widths only */
+void orc_cal_npart_hw_v3(int height, int width, int npart, const float *weight, int *tidx) {
+  int heights_per_part = height / npart;
+  float total = 0;
+  for (int i = 0; i < npart; i++) total += weight[i];
+  if (total > 3 * npart) {
+    for (int i = 0; i < npart; i++) tidx[i] = (int)(weight[i] / 64 * width + 0.5);
+    return;
+  }
+  float pi = acos(-1.0);
+  if (npart % 2 == 0) {
+    for (int i = 0; i < npart / 2 - 1; i++)
+      tidx[i] = (int)(weight[i] * width * cos(((heights_per_part * (i + 1) - 0.5) / height - 0.5) * pi) + 0.5);
+    tidx[npart / 2 - 1] = width;
+    tidx[npart / 2] = width;
+    for (int i = npart / 2 + 1; i < npart; i++)
+      tidx[i] = (int)(weight[i] * width * cos(((heights_per_part * i + 0.5) / height - 0.5) * pi) + 0.5);
+  } else {
+    for (int i = 0; i < npart / 2; i++)
+      tidx[i] = (int)(weight[i] * width * cos(((heights_per_part * (i + 1) - 0.5) / height - 0.5) * pi) + 0.5);
+    tidx[npart / 2] = width;
+    for (int i = npart / 2 + 1; i < npart; i++)
+      tidx[i] = (int)(weight[i] * width * cos(((heights_per_part * i + 0.5) / height - 0.5) * pi) + 0.5);
+  }
+}
+
+/* ---- sphere_slice_cuda.cu:13-32, 87-116 ---------------------------------- */
+/* hindex = tidx of v2 (2*npart ints).  param: 5 floats per (tile, column) */
+void orc_slice_param(int npart, int width, const int *hindex, float *param) {
+  int nthreads = npart * width;
+  for (int index = 0; index < nthreads; index++) {
+    int ti = index % width;
+    int tp = index / width;
+    int tw = hindex[npart + tp];
+    if (ti < tw) {
+      float nidx = (ti + 0.5) / tw * width - 0.5 + 1e-9;
+      nidx = (nidx < 0) ? nidx + width : nidx;
+      float nint = (float)((int)nidx);
+      float t = nidx - nint;
+      float t2 = t * t;
+      float t3 = t * t2;
+      param[index * 5] = nint;
+      param[index * 5 + 1] = (-t + 2 * t2 - t3) / 2;
+      param[index * 5 + 2] = (2 - 5 * t2 + 3 * t3) / 2;
+      param[index * 5 + 3] = (t + 4 * t2 - 3 * t3) / 2;
+      param[index * 5 + 4] = (-t2 + t3) / 2;
+    }
+  }
+}
+
+void orc_slice_forward(const float *input, float *output, const float *param, const int *hindex,
+                       int num_out, int channel, int height, int width, int height_in, int npart,
+                       int pad) {
+  const int stride_h = height + 2 * pad, stride_w = width + 2 * pad;
+  const i64 nthreads = (i64)num_out * channel * height * width;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int th = (index / width) % height;
+    int tc = (index / width / height) % channel;
+    int tn = index / width / height / channel;
+    i64 oidx = (((i64)tn * channel + tc) * stride_h + th + pad) * stride_w + tw + pad;
+    int pn = tn / npart;
+    int pt = tn % npart;
+    int ph = pt > 0 ? th + hindex[pt - 1] : th;
+    if (tw >= hindex[pt + npart]) {
+      output[oidx] = 0;
+      continue;
+    }
+    int base = (pt * width + tw) * 5;
+    int pw = (int)param[base];
+    i64 pidx = (((i64)pn * channel + tc) * height_in + ph) * width;
+    if (pw > 0 && pw < width - 2) {
+      output[oidx] = param[base + 1] * input[pidx + pw - 1] + param[base + 2] * input[pidx + pw] +
+                     param[base + 3] * input[pidx + pw + 1] + param[base + 4] * input[pidx + pw + 2];
+    } else {
+      output[oidx] = param[base + 1] * input[pidx + (pw - 1 + width) % width] +
+                     param[base + 2] * input[pidx + pw] +
+                     param[base + 3] * input[pidx + (pw + 1) % width] +
+                     param[base + 4] * input[pidx + (pw + 2) % width];
+    }
+  }
+}
+
+/* ---- sphere_uslice_cuda.cu:13-30, 73-99 ---------------------------------- */
+void orc_uslice_param(int npart, int width, const int *hindex, float *param) {
+  int nthreads = npart * width;
+  for (int index = 0; index < nthreads; index++) {
+    int ti = index % width;
+    int tp = index / width;
+    int tw = hindex[tp];
+    float nidx = (ti + 0.5) / width * tw - 0.5 + 1e-9;
+    nidx = (nidx < 0) ? nidx + tw : nidx;
+    float nint = (float)((int)nidx);
+    float t = nidx - nint;
+    float t2 = t * t;
+    float t3 = t * t2;
+    param[index * 5] = nint;
+    param[index * 5 + 1] = (-t + 2 * t2 - t3) / 2;
+    param[index * 5 + 2] = (2 - 5 * t2 + 3 * t3) / 2;
+    param[index * 5 + 3] = (t + 4 * t2 - 3 * t3) / 2;
+    param[index * 5 + 4] = (-t2 + t3) / 2;
+  }
+}
+
+void orc_uslice_forward(const float *input, float *output, const float *param, const int *hindex,
+                        int n_out, int channel, int height, int width, int npart, int pad) {
+  const int height_out = height * npart;
+  const int stride_h = height + 2 * pad, stride_w = width + 2 * pad;
+  const i64 nthreads = (i64)n_out * channel * height_out * width;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int th = (index / width) % height_out;
+    int tc = (index / width / height_out) % channel;
+    int tn = index / width / height_out / channel;
+    int ph = th % height;
+    int pb = th / height;
+    int pn = tn * npart + pb;
+    int base = (pb * width + tw) * 5;
+    int pw = (int)param[base];
+    i64 pidx = (((i64)pn * channel + tc) * stride_h + ph + pad) * stride_w + pad;
+    int wl = hindex[pb];
+    if (pw > 0 && pw < wl - 2) {
+      output[index] = param[base + 1] * input[pidx + pw - 1] + param[base + 2] * input[pidx + pw] +
+                      param[base + 3] * input[pidx + pw + 1] + param[base + 4] * input[pidx + pw + 2];
+    } else {
+      output[index] = param[base + 1] * input[pidx + (pw - 1 + wl) % wl] +
+                      param[base + 2] * input[pidx + pw] + param[base + 3] * input[pidx + (pw + 1) % wl] +
+                      param[base + 4] * input[pidx + (pw + 2) % wl];
+    }
+  }
+}
+
+/* ---- pseudo_context_cuda.cu:51-104 ---------------------------------------- */
+/* per index (tg, tl, tp, tw): dstoff/srcoff are the reference's param[0]/param[1]
+ * as exact integers; pcol = param[2]; pt = param[3]; hindex2 (npart*2*pad) */
+void orc_pseudo_context(const int *hindex, int *hindex2, i64 *dstoff, i64 *srcoff, int *pcol,
+                        float *pt, int channel, int height, int width, int npart, int pad) {
+  const int nthreads = npart * width * pad * 2;
+  for (int index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int tp = (index / width) % pad;
+    int tl = (index / width) / pad % 2;
+    int tg = index / width / pad / 2;
+    dstoff[index] = 0;
+    srcoff[index] = 0;
+    pcol[index] = 0;
+    pt[index] = 0;
+    if (tw >= hindex[tg]) continue;
+    int ph, pg;
+    float pw;
+    if (tl == 0) {
+      ph = tg * height - pad + tp;
+      if (ph < 0) {
+        ph = -ph - 1;
+        float nw;
+        nw = tw + hindex[tg] / 2.;
+        nw = (nw >= hindex[tg]) ? nw - hindex[tg] : nw;
+        pg = ph / height;
+        pw = (nw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+      } else {
+        pg = ph / height;
+        pw = (tw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+      }
+    } else {
+      ph = (tg + 1) * height + tp;
+      if (ph >= height * npart) {
+        ph = 2 * height * npart - ph - 1;
+        float nw;
+        nw = tw + hindex[tg] / 2.;
+        nw = (nw >= hindex[tg]) ? nw - hindex[tg] : nw;
+        pg = ph / height;
+        pw = (nw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+      } else {
+        pg = ph / height;
+        pw = (tw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+      }
+    }
+    pw = (pw < 0) ? pw + hindex[pg] : pw;
+    int pidx = (int)pw;
+    pcol[index] = pidx;
+    pt[index] = pidx + 1 - pw;
+    i64 d = (tl == 0) ? (i64)tg * channel * (height + pad * 2) + tp
+                      : (i64)tg * channel * (height + pad * 2) + pad + height + tp;
+    dstoff[index] = d * (width + pad * 2);
+    srcoff[index] = ((i64)pg * channel * height + ph % height) * width;
+    if (tw == 0) hindex2[(tg * 2 + tl) * pad + tp] = pg;
+  }
+}
+
+/* ---- pseudo_pad.cu:39-96 (three passes, as the reference launches them) --- */
+void orc_pseudo_pad(const float *input, float *output, const int *hindex, const int *hindex2,
+                    const i64 *dstoff, const i64 *srcoff, const int *pcol, const float *pt, int num,
+                    int channel, int height, int width, int npart, int pad) {
+  const int h_out = height + 2 * pad, w_out = width + 2 * pad;
+  i64 nthreads = (i64)num * channel * h_out * w_out;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) { /* pseudo_pad_copy_forward_kernel */
+    int pw = index % w_out;
+    int ph = (index / w_out) % h_out;
+    i64 ps = index / w_out / h_out;
+    int pg = (ps / channel) % npart;
+    if (pw < pad || pw >= hindex[pg] + pad || ph < pad || ph >= height + pad) {
+      output[index] = 0;
+      continue;
+    }
+    i64 tidx = (ps * height + ph - pad) * width + pw - pad;
+    output[index] = input[tidx];
+  }
+  const int inner_shape = 2 * pad * width;
+  const i64 astride = (i64)h_out * w_out, astride_out = astride * channel * npart;
+  const i64 bstride = (i64)height * width, bstride_out = bstride * channel * npart;
+  nthreads = (i64)num * channel * width * pad * 2;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) { /* pseudo_pad_forward_kernel */
+    int pw = index % width;
+    int ps = index % inner_shape;
+    int pc = (index / inner_shape) % channel;
+    int pn = index / inner_shape / channel;
+    int tn = pn / npart;
+    int tg = pn % npart;
+    if (pw >= hindex[tg]) continue;
+    int base = tg * inner_shape + ps;
+    i64 pbase = dstoff[base] + tn * astride_out + pc * astride;
+    i64 qbase = srcoff[base] + tn * bstride_out + pc * bstride;
+    int qw = pcol[base];
+    float t = pt[base];
+    int qg = hindex2[base / width];
+    int qww = (qw + 1) % hindex[qg];
+    output[pbase + pw + pad] = input[qbase + qw] * t + input[qbase + qww] * (1 - t);
+  }
+  const int pad2 = pad * 2;
+  nthreads = (i64)num * channel * h_out * pad * 2;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) { /* pseudo_pad_circle_forward_kernel */
+    int pw = index % pad2;
+    int pn = index / pad2 / h_out / channel;
+    int pg = pn % npart;
+    int pwa = pw % pad;
+    int pwb = pw / pad;
+    int wl = hindex[pg];
+    int qw = pwb * (wl + pad) + pwa;
+    i64 base = index / pad2 * w_out;
+    output[base + qw] = output[base + (qw - pad + wl) % wl + pad];
+  }
+}
+
+/* ---- pseudo_fill_cuda.cu:28-43 --------------------------------------------- */
+void orc_pseudo_fill(float *data, const int *hindex, int num, int channel, int height, int width,
+                     int npart, int pad, int trim, float fvalue) {
+  const i64 nthreads = (i64)num * channel * width * height;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) {
+    int pw = index % width;
+    int ph = (index / width) % height;
+    int pg = (index / width / height / channel) % npart;
+    if (ph < pad - trim || ph >= height - pad + trim) {
+      data[index] = fvalue;
+    } else {
+      if (pw < pad - trim || pw >= pad + hindex[pg] + trim) data[index] = fvalue;
+    }
+  }
+}
+
+/* ---- dtow_cuda.cu:38-75 ------------------------------------------------------ */
+void orc_dtow(const float *bottom_data, float *top_data, int num, int channels, int height, int width,
+              int patch_size, int d2w) {
+  const i64 nthreads = (i64)num * channels * height * width;
+  const int p2size = patch_size * patch_size;
+  int channels_out, height_out, width_out;
+  if (d2w) {
+    channels_out = channels / p2size;
+    height_out = height * patch_size;
+    width_out = width * patch_size;
+  } else {
+    channels_out = channels * p2size;
+    height_out = height / patch_size;
+    width_out = width / patch_size;
+  }
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int th = (index / width) % height;
+    int tc = (index / width / height) % channels;
+    int tn = index / width / height / channels;
+    int pc, ph, pw;
+    if (d2w) {
+      pc = tc / p2size;
+      int rc = tc % p2size;
+      ph = th * patch_size + rc / patch_size;
+      pw = tw * patch_size + rc % patch_size;
+    } else {
+      ph = th / patch_size;
+      pw = tw / patch_size;
+      pc = tc * p2size + (th % patch_size) * patch_size + tw % patch_size;
+    }
+    i64 pidx = (((i64)tn * channels_out + pc) * height_out + ph) * width_out + pw;
+    top_data[pidx] = bottom_data[index];
+  }
+}
+
+/* ---- pseudo_quant_cuda.cu:37-94 ------------------------------------------------ */
+void orc_quant_forward(const float *bottom, const float *weight_b, float *weight, int *quant, float *top,
+                       float *top_idx, float *count, const int *hindex, int num, int channels, int height,
+                       int width, int levels, int npart) {
+  for (int index = 0; index < channels * levels; index++) { /* pseudo_quant_cal_weight_kernel */
+    if (index % levels == 0)
+      weight[index] = weight_b[index];
+    else
+      weight[index] = o_expf(weight_b[index]);
+  }
+  const int inner_shape = width * height;
+  const i64 total = (i64)num * channels * inner_shape;
+  for (i64 i = 0; i < total; i++) { /* pseudo_quant_single_gpu_forward_kernel */
+    int pw = i % width;
+    int pg = (i / inner_shape / channels) % npart;
+    if (pw >= hindex[pg]) {
+      top[i] = 0;
+      quant[i] = 0;
+      continue;
+    }
+    int pc = (i / inner_shape) % channels;
+    float tmp = bottom[i] - weight[pc * levels];
+    if (tmp < 0) {
+      quant[i] = 0;
+      top[i] = weight[pc * levels];
+      if (count) count[pc * levels] += -1.0f;
+      continue;
+    }
+    int j = 1;
+    for (; j < levels; j++) {
+      tmp -= weight[pc * levels + j];
+      if (tmp < 0) break;
+    }
+    if (j == levels) j--;
+    if (tmp + tmp + weight[pc * levels + j] < 0) {
+      tmp = tmp + weight[pc * levels + j];
+      j--;
+    }
+    top[i] = bottom[i] - tmp;
+    quant[i] = j;
+    if (count) count[pc * levels + j] += -1.0f;
+  }
+  if (top_idx)
+    for (i64 i = 0; i < total; i++) top_idx[i] = quant[i]; /* pseudo_quant_gpu_copy */
+}
+
+/* ---- pseudo_dquant_cuda.cu:24-47 ------------------------------------------------- */
+void orc_dquant_forward(const float *input, const float *weight_in, float *weight, float *output,
+                        const int *hindex, int num, int channel, int height, int width, int nchannel,
+                        int level, int npart) {
+  for (int index = 0; index < nchannel; index++) {
+    weight[index * level] = weight_in[index * level];
+    for (int i = 1; i < level; i++)
+      weight[index * level + i] = weight[index * level + i - 1] + o_expf(weight_in[index * level + i]);
+  }
+  const int inner_shape = width * height;
+  const i64 nthreads = (i64)num * channel * inner_shape;
+  for (i64 index = 0; index < nthreads; index++) {
+    int pw = index % width;
+    int pg = (index / inner_shape / channel) % npart;
+    if (pw >= hindex[pg]) {
+      output[index] = 0;
+      continue;
+    }
+    int tc = (index / inner_shape) % channel;
+    int idx = (int)(input[index] + 0.00001);
+    output[index] = weight[tc * level + idx];
+  }
+}
+
+/* ---- projects_cuda.cu:7-165, 181-213 ------------------------------------------------ */
+static void o_mrod(const float *x, const float *y, const float *z, float *data, int n) {
+  for (int i = 0; i < n; i++) {
+    int base = i * 9;
+    for (int k = 0; k < 9; k++) data[base + k] = 0;
+    float norm = sqrt(x[i] * x[i] + y[i] * y[i] + z[i] * z[i]);
+    if (norm == 0) {
+      data[base] = 1.;
+      data[base + 4] = 1.;
+      data[base + 8] = 1.;
+      continue;
+    }
+    float tx = x[i] / norm, ty = y[i] / norm, tz = z[i] / norm;
+    float c = cos(norm), s = sin(norm);
+    data[base + 0] = c + (1 - c) * tx * tx;
+    data[base + 1] = (1 - c) * tx * ty - s * tz;
+    data[base + 2] = (1 - c) * tx * tz + s * ty;
+    data[base + 3] = (1 - c) * ty * tx + s * tz;
+    data[base + 4] = c + (1 - c) * ty * ty;
+    data[base + 5] = (1 - c) * ty * tz - s * tx;
+    data[base + 6] = (1 - c) * tz * tx - s * ty;
+    data[base + 7] = (1 - c) * tz * ty + s * tx;
+    data[base + 8] = c + (1 - c) * tz * tz;
+  }
+}
+
+/* builds tf (nv*h_out*w_out*2) for an ERP of height x width */
+void orc_projects_table(const float *theta_in, const float *phi_in, int nv, float fov_in, int h_out,
+                        int w_out, int height, int width, float *tf) {
+  float pi_ = acos(-1.0);
+  float *theta = (float *)malloc(sizeof(float) * nv), *phi = (float *)malloc(sizeof(float) * nv);
+  for (int i = 0; i < nv; i++) {
+    theta[i] = theta_in[i] * pi_;
+    phi[i] = phi_in[i] * pi_;
+  }
+  float fov_ = fov_in * pi_;
+  const int inner = h_out * w_out;
+  float *xyz = (float *)malloc(sizeof(float) * nv * inner * 3);
+  float hfov = fov_ * h_out / w_out / 2;
+  float wfov = fov_ / 2;
+  float c_x = (w_out - 1) / 2.0;
+  float c_y = (h_out - 1) / 2.0;
+  float pi_2 = pi_ / 2;
+  float wangle = pi_2 - wfov;
+  float hangle = pi_2 - hfov;
+  float w_stride = 2 * sin(wfov) / sin(wangle) / (w_out - 1);
+  float h_stride = 2 * sin(hfov) / sin(hangle) / (h_out - 1);
+  for (int i = 0; i < nv * inner; i++) { /* projects_init_xyz_kernel */
+    int w = i % w_out;
+    int h = (i / w_out) % h_out;
+    float x = 1.;
+    float y = (w - c_x) * w_stride;
+    float z = (h - c_y) * h_stride;
+    float r = sqrt(x * x + y * y + z * z);
+    xyz[i * 3] = x / r;
+    xyz[i * 3 + 1] = y / r;
+    xyz[i * 3 + 2] = -z / r;
+  }
+  float *r1 = (float *)malloc(sizeof(float) * nv * 9), *r2 = (float *)malloc(sizeof(float) * nv * 9);
+  float *r = (float *)malloc(sizeof(float) * nv * 9);
+  float *xa = (float *)malloc(sizeof(float) * nv), *ya = (float *)malloc(sizeof(float) * nv),
+        *za = (float *)malloc(sizeof(float) * nv);
+  for (int i = 0; i < nv; i++) {
+    xa[i] = 0;
+    ya[i] = 0;
+    za[i] = theta[i];
+  }
+  o_mrod(xa, ya, za, r1, nv);
+  for (int i = 0; i < nv; i++) {
+    xa[i] = r1[i * 9 + 1] * (-phi[i]);
+    ya[i] = r1[i * 9 + 4] * (-phi[i]);
+    za[i] = r1[i * 9 + 7] * (-phi[i]);
+  }
+  o_mrod(xa, ya, za, r2, nv);
+  for (int i = 0; i < nv * 9; i++) { /* gmm_kernel: r = r2 x r1 */
+    int tm = (i / 3) % 3, tn = i % 3, tb = i / 9;
+    float sum = 0;
+    for (int j = 0; j < 3; j++) sum += r2[tb * 9 + tm * 3 + j] * r1[tb * 9 + j * 3 + tn];
+    r[tb * 9 + tm * 3 + tn] = sum;
+  }
+  for (int i = 0; i < nv * inner; i++) { /* gmm_transpose_kernel */
+    int tb = i / inner, tm = i % inner;
+    int base_x = tb * inner * 3, base_y = tb * 9;
+    float a = xyz[base_x + tm * 3], b = xyz[base_x + tm * 3 + 1], c = xyz[base_x + tm * 3 + 2];
+    xyz[base_x + tm * 3] = a * r[base_y] + b * r[base_y + 1] + c * r[base_y + 2];
+    xyz[base_x + tm * 3 + 1] = a * r[base_y + 3] + b * r[base_y + 4] + c * r[base_y + 5];
+    xyz[base_x + tm * 3 + 2] = a * r[base_y + 6] + b * r[base_y + 7] + c * r[base_y + 8];
+  }
+  float hx = (width - 1) / 2.0;
+  float hy = (height - 1) / 2.0;
+  for (int i = 0; i < nv * inner; i++) { /* projects_cal_xyz_kernel */
+    float lat = asin(xyz[i * 3 + 2]);
+    float tx = xyz[i * 3];
+    float ty = xyz[i * 3 + 1];
+    float th = atan(ty / tx);
+    if (tx <= 0) {
+      if (ty > 0)
+        th = th + pi_;
+      else
+        th = th - pi_;
+    }
+    tf[i * 2] = th / pi_ * hx + hx;
+    tf[i * 2 + 1] = -2 * lat / pi_ * hy + hy;
+  }
+  free(theta); free(phi); free(xyz); free(r1); free(r2); free(r); free(xa); free(ya); free(za);
+}
+
+void orc_projects_forward(const float *input, const float *tf, float *output, int num, int channel,
+                          int hs, int ws, int nv, int h_out, int w_out, int nearest) {
+  const int inner_shape = h_out * w_out, out_shape = num * channel;
+  const i64 nthreads = (i64)out_shape * inner_shape * nv;
+#pragma omp parallel for
+  for (i64 index = 0; index < nthreads; index++) {
+    int ps = index % inner_shape;
+    int tn = (index / inner_shape) % out_shape;
+    int tb = index / inner_shape / out_shape;
+    int base = tb * 2 * inner_shape;
+    if (nearest) {
+      int tw = (int)(floor(tf[base + 2 * ps] + 0.5)) % ws;
+      int th = (int)(floor(tf[base + 2 * ps + 1] + 0.5));
+      th = th >= hs ? hs - 1 : th;
+      output[index] = input[((i64)tn * hs + th) * ws + tw];
+    } else {
+      int tw = (int)(floor(tf[base + 2 * ps]));
+      int th = (int)(floor(tf[base + 2 * ps + 1]));
+      int pw = (tw + 1) % ws;
+      int ph = th + 1 >= hs ? hs - 1 : th + 1;
+      float tx = tf[base + 2 * ps] - tw;
+      float ty = tf[base + 2 * ps + 1] - th;
+      float ntx = 1. - tx;
+      float nty = 1. - ty;
+      output[index] = input[((i64)tn * hs + th) * ws + tw] * ntx * nty +
+                      input[((i64)tn * hs + th) * ws + pw] * tx * nty +
+                      input[((i64)tn * hs + ph) * ws + tw] * ntx * ty +
+                      input[((i64)tn * hs + ph) * ws + pw] * tx * ty;
+    }
+  }
+}
+
+/* ---- context_reshape_cuda.cu:30-39 ---------------------------------------------------- */
+void orc_context_reshape(const float *bottom, float *top, int num, int channel, int height, int width,
+                         int cpg) {
+  const int inner_size = height * width;
+  const i64 nthreads = (i64)num * channel * inner_size;
+  for (i64 index = 0; index < nthreads; index++) {
+    i64 pn = index / inner_size / channel;
+    int pc = (index / inner_size) % channel;
+    int ps = index % inner_size;
+    i64 tidx = (pn * inner_size * channel / cpg + (i64)(pc / cpg) * inner_size + ps) * cpg + pc % cpg;
+    top[tidx] = bottom[index];
+  }
+}
+
+/* ---- mask_constrain_cuda.cu:19-88 -------------------------------------------------------- */
+void orc_mask_constrain(float *weight, int num, int channel, int sz, int ngroup, int constrain) {
+  const int group_in = channel / ngroup, group_out = num / ngroup;
+  const int nthreads = num * channel * sz * sz;
+  for (int index = 0; index < nthreads; index++) {
+    int tw = index % sz;
+    int th = (index / sz) % sz;
+    int tc = (index / sz / sz) % channel / group_in;
+    int tn = index / sz / sz / channel / group_out;
+    if (constrain == 1 || constrain == 2) {
+      if (tn > tc) continue;
+      if (tn == tc) {
+        if (th < sz / 2)
+          continue;
+        else if (th == sz / 2) {
+          if (constrain == 1 ? (tw < sz / 2) : (tw <= sz / 2))
+            continue;
+          else
+            weight[index] = 0;
+        } else
+          weight[index] = 0;
+      } else
+        weight[index] = 0;
+    } else if (constrain == 5) {
+      if (tw + th + tc >= tn + sz - 1) weight[index] = 0;
+    } else {
+      if (tw + th + tc > tn + sz - 1) weight[index] = 0;
+    }
+  }
+}
+
+/* ---- entropy_gmm_cuda.cu:36-69 (loss only + the stored gradients) ------------------------- */
+void orc_gmm_loss(const float *bottom_weight, const float *bottom_delta, const float *bottom_mean,
+                  const float *label, float *weight_diff, float *delta_diff, float *mean_diff,
+                  float *label_diff, float *loss, int nthreads, int ng) {
+  for (int index = 0; index < nthreads; index++) {
+    float s2 = 1. / sqrt((float)2.0);
+    float sp2 = 1. / sqrt(2. * acos(-1.0));
+    float sum_p = 0;
+    label_diff[index] = 0;
+    for (int i = 0; i < ng; i++) {
+      float xa = label[index] - 0.5 - bottom_mean[index * ng + i];
+      float xb = label[index] + 0.5 - bottom_mean[index * ng + i];
+      float id = 1. / bottom_delta[index * ng + i];
+      float fa = 0.5 + 0.5 * o_erff(xa * id * s2);
+      float fb = 0.5 + 0.5 * o_erff(xb * id * s2);
+      float p = fb - fa;
+      sum_p = sum_p + bottom_weight[index * ng + i] * p;
+      float ga = sp2 * id * o_expf(-0.5 * xa * xa * id * id);
+      float gb = sp2 * id * o_expf(-0.5 * xb * xb * id * id);
+      label_diff[index] += (gb - ga) * bottom_weight[index * ng + i];
+      delta_diff[index * ng + i] = id * (-xb * gb + xa * ga) * bottom_weight[index * ng + i];
+      mean_diff[index * ng + i] = (ga - gb) * bottom_weight[index * ng + i];
+      weight_diff[index * ng + i] = p;
+    }
+    loss[index] = -log(sum_p + 0.0000001);
+    float ip = -1. / (sum_p + 0.0000001);
+    label_diff[index] *= ip;
+    for (int i = 0; i < ng; i++) {
+      delta_diff[index * ng + i] *= ip;
+      mean_diff[index * ng + i] *= ip;
+      weight_diff[index * ng + i] *= ip;
+    }
+  }
+}
+
+/* ---- entropy_context_cuda.cu:13-45 ----------------------------------------------------------- */
+void orc_wavefront(const int *hindex, int npart, int height_, int w_out_, int *idx, int *start_idx) {
+  const int h_out_ = height_ * npart;
+  int index = 0, jidx = 0;
+  for (int ps = 0; ps < h_out_ + w_out_ - 1; ps++) {
+    start_idx[jidx] = index;
+    jidx++;
+    for (int i = 0; i < h_out_; i++) {
+      int j = ps - i;
+      if (j < 0 || j >= hindex[i / height_]) continue;
+      idx[index] = i * w_out_ + j;
+      index++;
+    }
+  }
+  start_idx[jidx] = index;
+}
+
+/* ---- entropy_context_cuda.cu:105-165 (table), 64-103 (plane lists), 187-204 (compaction) ------ */
+/* table per index (tg,tl,tp,tw): dstoff, srcoff (padded layout), pcol (-1 = none), pt;
+ * hindex2 (-1 = no neighbour).  Then per-plane lists in loop order:
+ * list[k] = {a, b, plane}: b < 0 -> a is a table index, else copy dst=a src=b.
+ * pad_idx[h_out+w_out+2pad] prefix offsets.  Returns the number of list entries. */
+int orc_entropy_context(const int *hindex, int *hindex2, i64 *dstoff, i64 *srcoff, int *pcol, float *pt,
+                        i64 *list, int list_cap, int *pad_idx, int channel, int height, int width,
+                        int npart, int pad) {
+  const int nthreads = npart * width * pad * 2;
+  const int h_out = height * npart;
+  for (int i = 0; i < npart * 2 * pad; i++) hindex2[i] = 0;
+  for (int index = 0; index < nthreads; index++) { /* entropy_context_kernel */
+    int tw = index % width;
+    int tp = (index / width) % pad;
+    int tl = (index / width) / pad % 2;
+    int tg = index / width / pad / 2;
+    dstoff[index] = 0;
+    srcoff[index] = 0;
+    pcol[index] = 0;
+    pt[index] = 0;
+    if (tw >= hindex[tg]) continue;
+    int ph, pg = 0;
+    float pw = 0;
+    int bound = 0;
+    if (tl == 0) {
+      ph = tg * height - pad + tp;
+      if (ph < 0) {
+        bound = 1;
+      } else {
+        pg = ph / height;
+        pw = (tw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+      }
+    } else {
+      ph = (tg + 1) * height + tp;
+      if (ph >= height * npart) {
+        bound = 1;
+      } else {
+        pg = ph / height;
+        pw = (tw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+      }
+    }
+    i64 d = (tl == 0) ? (i64)tg * channel * (height + pad * 2) + tp
+                      : (i64)tg * channel * (height + pad * 2) + pad + height + tp;
+    dstoff[index] = d * (width + pad * 2);
+    if (bound) {
+      if (tw == 0) hindex2[(tg * 2 + tl) * pad + tp] = -1;
+    } else {
+      srcoff[index] = ((i64)pg * channel * (height + pad * 2) + pad + ph % height) * (width + pad * 2);
+      int pidx = pw < 0 ? -1 : (int)pw;
+      if (pidx > tw) {
+        pcol[index] = -1;
+        pt[index] = 1.;
+      } else if (pidx + 1 > tw) {
+        pcol[index] = pidx;
+        pt[index] = 1.;
+      } else {
+        pcol[index] = pidx;
+        pt[index] = pidx + 1 - pw;
+        if (pidx == -1) pt[index] = 0.;
+      }
+      if (tw == 0) hindex2[(tg * 2 + tl) * pad + tp] = pg;
+    }
+  }
+  /* plane lists: two passes (count, fill) instead of atomics */
+  const int nplane = h_out + width + 2 * pad;
+  int *count = (int *)calloc(nplane, sizeof(int));
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      pad_idx[0] = 0;
+      for (int i = 0; i < nplane - 1; i++) pad_idx[i + 1] = pad_idx[i] + count[i];
+      if (pad_idx[nplane - 1] + count[nplane - 1] > list_cap) {
+        free(count);
+        return -1;
+      }
+      memset(count, 0, nplane * sizeof(int));
+    }
+    for (int index = 0; index < nthreads; index++) { /* entropy_context_step1 */
+      int tw = index % width;
+      int tp = (index / width) % pad;
+      int tl = (index / width) / pad % 2;
+      int tg = index / width / pad / 2;
+      if (tw >= hindex[tg]) continue;
+      if (hindex2[(tg * 2 + tl) * pad + tp] < 0) continue;
+      if (pcol[index] < 0 && pt[index] >= 1 - 1e-6) continue;
+      int ph = (tl == 0) ? tg * height - pad + tp : (tg + 1) * height + tp;
+      int plane = ph + tw;
+      if (pass == 1) {
+        i64 *e = list + (i64)(pad_idx[plane] + count[plane]) * 3;
+        e[0] = index;
+        e[1] = -1;
+        e[2] = plane;
+      }
+      count[plane]++;
+    }
+    const int n2 = npart * (height + 2 * pad) * pad;
+    for (int index = 0; index < n2; index++) { /* entropy_context_step2 */
+      int qh = height + 2 * pad;
+      int tw = index % pad;
+      int th = (index / pad) % qh;
+      int tg = index / pad / qh;
+      int ph = tg * height + th - pad;
+      if (ph < 0 || ph >= height * npart) continue;
+      int wp = hindex[tg];
+      int plane = ph + tw + wp;
+      i64 base = ((i64)tg * channel * qh + th) * (width + 2 * pad) + tw + pad;
+      if (pass == 1) {
+        i64 *e = list + (i64)(pad_idx[plane] + count[plane]) * 3;
+        e[0] = base + wp;
+        e[1] = base;
+        e[2] = plane;
+      }
+      count[plane]++;
+    }
+  }
+  int total = pad_idx[nplane - 1] + count[nplane - 1];
+  free(count);
+  return total;
+}
+
+/* ---- d_input_cuda_v2.cu:32-52 ------------------------------------------------------------------- */
+void orc_dinput2(const float *input, const int *index, float *output, int num, int start_idx, int len_idx,
+                 int height, int width, int channel, int npart, int psum, int pad, float bias, int rep,
+                 i64 stride_out) {
+  const int hout = height + 2 * pad, wout = width + 2 * pad;
+  for (int i = 0; i < num; i++) {
+    int tl = i % len_idx;
+    int tn = i / len_idx;
+    int thw = index[tl + start_idx];
+    int tw = thw % width;
+    int tha = thw / width;
+    int tg = tha / height;
+    int th = tha % height;
+    int tc = psum - tw - tha;
+    i64 pidx = ((((i64)tn * npart + tg) * channel + tc) * hout + th + pad) * wout + tw + pad;
+    float tmp = input[i] + bias;
+    for (int j = 0; j < rep; j++) output[pidx + j * stride_out] = tmp;
+  }
+}
+
+/* ---- entropy_ctx_pad_run2_cuda.cu:33-65 ----------------------------------------------------------- */
+void orc_ctx_pad_run2(float *data, const i64 *dstoff, const i64 *srcoff, const int *pcol, const float *pt,
+                      const i64 *list, const int *hindex, const int *hindex2, int nthreads, int psum,
+                      int start_idx, int ntile, int cpn, i64 astride, i64 astride_out, int width, int pad) {
+  const float *input = data;
+  float *output = data;
+  for (int index = 0; index < nthreads; index++) {
+    int pa = index % ntile;
+    const i64 *e = list + (i64)(start_idx + pa) * 3;
+    int ppc = (index / ntile) % cpn;
+    int tn = index / ntile / cpn;
+    int pc = (psum - (int)e[2]) * cpn + ppc;
+    i64 pbase, qbase;
+    if (e[1] < 0) {
+      int tbase = (int)e[0];
+      int pw = tbase % width;
+      int qg = hindex2[tbase / width];
+      pbase = dstoff[tbase] + tn * astride_out + pc * astride;
+      qbase = srcoff[tbase] + tn * astride_out + pc * astride;
+      int qw = pcol[tbase] >= 0 ? pcol[tbase] : -1;
+      float qdata = (qw == -1) ? 0 : input[qbase + qw + pad];
+      float t = pt[tbase];
+      int qww = (qw + 1) % hindex[qg];
+      output[pbase + pw + pad] = qdata * t + input[qbase + qww + pad] * (1 - t);
+    } else {
+      pbase = e[0] + tn * astride_out + pc * astride;
+      qbase = e[1] + tn * astride_out + pc * astride;
+      output[pbase] = output[qbase];
+    }
+  }
+}
+
+/* ---- entropy_conv_cuda_v2.cu:326-380 ----------------------------------------------------------------- */
+/* order = 0: the reference's own summation order (128 threads striding over
+ *            25*group_in, each looping over the allowed groups; shared-memory
+ *            halving 128->64->32, then shuffle-down 16..1);
+ * order = 1: the product's published order (64 lanes striding over the flattened
+ *            (ci,kh,kw) index with fmaf, xor-butterfly 32..1). */
+static float reduce_ref128(float *s) {
+  for (int t = 0; t < 64; t++) s[t] = s[t] + s[t + 64];
+  for (int t = 0; t < 32; t++) s[t] = s[t] + s[t + 32];
+  for (int off = 16; off > 0; off /= 2)
+    for (int t = 0; t < off; t++) s[t] = s[t] + s[t + off];
+  return s[0];
+}
+static float reduce_xor64(float *s) {
+  float tmp[64];
+  for (int off = 32; off > 0; off >>= 1) {
+    for (int t = 0; t < 64; t++) tmp[t] = s[t] + s[t ^ off];
+    memcpy(s, tmp, sizeof(tmp));
+  }
+  return s[0];
+}
+
+void orc_entropy_conv(const float *input, const float *weight, const float *bias, const float *act_param,
+                      float *output, const int *mindex, int kernel_size, int group_in, int group_out,
+                      int height, int width, int start_idx, int psum, int inner_shape, int channel, int nout,
+                      int npart, int pad_in, int pad_out, int constrain, int num_out, int num_per_batch,
+                      int order) {
+  const int skernel = kernel_size * kernel_size, half_kernel = kernel_size / 2;
+  const i64 index_stride = (i64)(height + 2 * pad_in) * (width + 2 * pad_in);
+  const int nblocks = num_out * group_out * inner_shape;
+#pragma omp parallel for
+  for (int block = 0; block < nblocks; block++) {
+    int pb = block % inner_shape;
+    int og = (block / inner_shape) % group_out;
+    int pn = block / inner_shape / group_out;
+    int nbatch = pn / num_per_batch;
+    int hw = mindex[pb + start_idx];
+    int tw = hw % width;
+    int hp = hw / width;
+    int tg = hp / height;
+    int th = hp % height;
+    int qn = pn * npart + tg;
+    int tc = psum - tw - hp;
+    int pout = tc * group_out + og;
+    float part[128];
+    float sum;
+    if (order == 0) {
+      const int nblock = skernel * group_in;
+      for (int tid = 0; tid < 128; tid++) {
+        float s = 0;
+        for (int index = tid; index < nblock; index += 128) {
+          int kw = index % kernel_size;
+          int kh = (index / kernel_size) % kernel_size;
+          int gid = index / kernel_size / kernel_size;
+          int ph = th - half_kernel + kh;
+          int qh = hp - half_kernel + kh;
+          int pw = tw - half_kernel + kw;
+          int nchannel = constrain == 5 ? (psum - qh - pw) * group_in : (psum - qh - pw + 1) * group_in;
+          if (nchannel > channel) nchannel = channel;
+          if (nchannel > 0) {
+            i64 weight_base = (((i64)nbatch * nout + pout) * channel * kernel_size + kh) * kernel_size + kw;
+            i64 data_base = ((i64)qn * channel * (height + 2 * pad_in) + ph + pad_in) * (width + 2 * pad_in) + pw + pad_in;
+            for (int ti = gid; ti < nchannel; ti += group_in)
+              s = s + input[data_base + ti * index_stride] * weight[weight_base + (i64)ti * skernel];
+          }
+        }
+        part[tid] = s;
+      }
+      sum = reduce_ref128(part);
+    } else {
+      const int red = channel * skernel;
+      const float *wrow = weight + ((i64)nbatch * nout + pout) * red;
+      for (int lane = 0; lane < 64; lane++) {
+        float s = 0;
+        for (int kk = lane; kk < red; kk += 64) {
+          int kw = kk % kernel_size;
+          int kh = (kk / kernel_size) % kernel_size;
+          int ci = kk / skernel;
+          int qh = hp - half_kernel + kh;
+          int pw = tw - half_kernel + kw;
+          int nchannel = constrain == 5 ? (psum - qh - pw) * group_in : (psum - qh - pw + 1) * group_in;
+          if (ci < nchannel) {
+            i64 d = ((i64)qn * channel + ci) * index_stride + (i64)(th - half_kernel + kh + pad_in) * (width + 2 * pad_in) + pw + pad_in;
+            s = fmaf(input[d], wrow[kk], s);
+          }
+        }
+        part[lane] = s;
+      }
+      sum = reduce_xor64(part);
+    }
+    i64 out_idx = (((i64)qn * nout + pout) * (height + 2 * pad_out) + th + pad_out) * (width + 2 * pad_out) + tw + pad_out;
+    int bidx = nbatch * nout + pout;
+    sum = sum + bias[bidx];
+    if (act_param && sum < 0) sum = sum * act_param[bidx];
+    output[out_idx] = sum;
+  }
+}
+
+/* ---- entropy_add_cuda.cu:25-44 -------------------------------------------------------------------------- */
+void orc_entropy_add(float *output, const float *input, const int *mindex, int count, int group_out,
+                     int start_idx, int psum, int height, int width, int nout, int num, int npart, int pad,
+                     int inner_shape) {
+  for (int index = 0; index < count; index++) {
+    int pn = index % num;
+    int pp = index / num;
+    int pb = pp % inner_shape;
+    int hw = mindex[pb + start_idx];
+    int tw = hw % width;
+    int hp = hw / width;
+    int tg = hp / height;
+    int th = hp % height;
+    int tc = psum - tw - hp;
+    int og = pp / inner_shape;
+    int pout = (tc * group_out + og);
+    int qn = pn * npart + tg;
+    i64 out_idx = (((i64)qn * nout + pout) * (height + 2 * pad) + th + pad) * (width + 2 * pad) + tw + pad;
+    output[out_idx] = output[out_idx] + input[out_idx];
+  }
+}
+
+/* ---- d_extract_cuda_v2.cu:34-52, 110-132 -------------------------------------------------------------------- */
+void orc_dextract2(const float *input, const int *index, float *output, int num, int start_idx, int len_idx,
+                   int height, int width, int channel, int cpn, int npart, int psum, i64 stride,
+                   int inner_shape) {
+  for (int i = 0; i < num; i++) {
+    int ci = i % cpn;
+    int tl = (i / cpn) % len_idx;
+    int tn = i / cpn / len_idx;
+    int thw = index[tl + start_idx];
+    int tw = thw % width;
+    int tha = thw / width;
+    int tg = tha / height;
+    int th = tha % height;
+    int tc = psum - tw - tha;
+    i64 pidx = ((((i64)tn * npart + tg) * channel + tc * cpn + ci) * height + th) * width + tw;
+    if (inner_shape > 0) {
+      int ps = i % inner_shape;
+      int pn = i / inner_shape;
+      output[pn * stride + ps] = input[pidx];
+    } else {
+      output[i] = input[pidx];
+    }
+  }
+}
+
+/* ---- entropy_gmm_table_cuda.cu:29-57, 59-80, 83-105, 136-153 --------------------------------------------------- */
+void orc_gmm_table(float *weight, float *delta, const float *mean, float *output, int tn, int w, int nstep,
+                   float bias, float total, float beta, int batch) {
+  float tmp[16];
+  for (int index = 0; index < tn; index++) { /* entropy_gmm_table_weight_kernel */
+    int pbase = index * w;
+    float mval = -1e10, psum = 0;
+    for (int i = 0; i < w; i++) {
+      tmp[i] = weight[pbase + i];
+      if (mval < tmp[i]) mval = tmp[i];
+    }
+    for (int i = 0; i < w; i++) {
+      tmp[i] = o_expf(tmp[i] - mval);
+      psum += tmp[i];
+    }
+    for (int i = 0; i < w; i++) weight[pbase + i] = tmp[i] / psum;
+  }
+  for (int index = 0; index < tn * w; index++) { /* entropy_gmm_table_delta_kernel */
+    float t = delta[index];
+    t = t < 0 ? beta : t + beta;
+    delta[index] = t;
+  }
+  const int ntable = nstep + 1;
+  const float s2 = 1. / sqrt(2.0);
+  for (int index = 0; index < tn * ntable; index++) {
+    int pt = index % ntable;
+    int pn = index / ntable;
+    if (pt == 0) {
+      output[index] = 0;
+    } else if (pt == ntable - 1) {
+      output[index] = (int)(total);
+    } else {
+      float v = pt - 1 - bias + 0.5, ps = 0, f;
+      for (int i = 0; i < w; i++) {
+        if (batch) { /* entropy_gmm_table_batch_forward_kernel: double inside */
+          ps = ps + weight[pn * w + i] * (0.5 + 0.5 * o_erff(s2 * (v - mean[pn * w + i]) / delta[pn * w + i]));
+        } else { /* entropy_gmm_table_forward_kernel: f rounded to float */
+          f = 0.5 + 0.5 * o_erff(s2 * (v - mean[pn * w + i]) / delta[pn * w + i]);
+          ps = ps + weight[pn * w + i] * f;
+        }
+      }
+      output[index] = (int)(total * ps + 0.5);
+    }
+  }
+  const int ngroup = nstep;
+  for (int index = 0; index < tn; index++) { /* entropy_gmm_table_check_kernel */
+    float b = 0;
+    float mval = 0;
+    int midx = 0;
+    for (int i = 0; i < ngroup; i++) {
+      if (output[index * (ngroup + 1) + i + 1] <= output[index * (ngroup + 1) + i]) b += 1;
+      output[index * (ngroup + 1) + i + 1] += b;
+      if (output[index * (ngroup + 1) + i + 1] - output[index * (ngroup + 1) + i] > mval) {
+        mval = output[index * (ngroup + 1) + i + 1] - output[index * (ngroup + 1) + i];
+        midx = i;
+      }
+    }
+    if (b > 0)
+      for (int i = midx; i < ngroup; i++) output[index * (ngroup + 1) + i + 1] -= b;
+  }
+}
+
+/* ---- dense conv: k-ascending fp32 fmaf chain (the product's published order for
+ * the nn.Conv2d call sites; torch.nn.functional.conv2d is the 1e-4 reference) ---- */
+void orc_conv2d_chain(const float *in, const float *w, const float *bias, const float *slope, float *out,
+                      int tn, int cin, int h, int wd, int cout, int k, int stride) {
+  const int ho = (h - k) / stride + 1, wo = (wd - k) / stride + 1;
+  const i64 total = (i64)tn * cout * ho * wo;
+#pragma omp parallel for
+  for (i64 o = 0; o < total; o++) {
+    int ox = o % wo;
+    int oy = (o / wo) % ho;
+    int co = (o / wo / ho) % cout;
+    i64 t = o / wo / ho / cout;
+    float acc = 0.f;
+    for (int ci = 0; ci < cin; ci++)
+      for (int kh = 0; kh < k; kh++)
+        for (int kw = 0; kw < k; kw++)
+          acc = fmaf(w[(((i64)co * cin + ci) * k + kh) * k + kw],
+                     in[((t * cin + ci) * h + oy * stride + kh) * wd + ox * stride + kw], acc);
+    if (bias) acc = acc + bias[co];
+    if (slope && acc < 0) acc = acc * slope[co];
+    out[o] = acc;
+  }
+}

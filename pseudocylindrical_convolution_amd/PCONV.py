@@ -1,0 +1,869 @@
+"""`PCONV` -- the native-module surface of the reference, on MI355X.
+
+The reference binds 21 stateful C++ op classes with pybind11
+(extension/main.cpp:4-137).  This module offers the same classes, constructor
+signatures and methods; each one owns its output buffers, step counters and
+table caches exactly like the reference's `base_opt` objects
+(extension/base_opt.hpp:4-81) and launches the hand-written HIP kernels of
+libpconv_hip.so through the C ABI in include/pconv_hip.h.
+
+There is no CPU path here: every forward needs the HIP library and a GPU tensor.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import PconvError, call
+
+__all__ = [
+    "ProjectsOp", "DtowOp", "ContextReshapeOp", "EntropyGmmOp", "MaskConstrainOp",
+    "SphereSliceOp", "SphereUsliceOp", "EntropyGmmTableOp", "EntropyContextOp",
+    "EntropyCtxPadRun2Op", "DExtract2Op", "DInput2Op", "EntropyConv2Op", "PseudoContextOp",
+    "PseudoPadOp", "PseudoFillOp", "PseudoEntropyContextOp", "PseudoEntropyPadOp",
+    "PseudoQuantOp", "PseudoDQuantOp", "EntropyAddOp",
+]
+
+# addr() string -> context object (string2class.cc:2-22 parses a raw pointer;
+# here the string is an opaque key and borrowers keep a strong reference)
+_contexts = weakref.WeakValueDictionary()
+
+
+def _lookup(addr):
+    try:
+        return _contexts[addr]
+    except KeyError:
+        raise PconvError("no live context object for address %r" % (addr,))
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _np_ptr(a):
+    return a.ctypes.data
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(x, what):
+    if not x.is_cuda:
+        raise PconvError("%s: expected a GPU tensor (this build has no CPU path), got %s" % (what, x.device))
+    if x.dtype != torch.float32:
+        raise PconvError("%s: only float32 is supported, got %s" % (what, x.dtype))
+    if not x.is_contiguous():
+        raise PconvError("%s: input must be contiguous" % what)
+
+
+def tile_widths(weight, npart, height, width):
+    """Valid width of each latitude tile (math_cuda.cu:223-253)."""
+    w = np.ascontiguousarray(weight, dtype=np.float32)
+    out = np.zeros(npart, dtype=np.int32)
+    call("pconv_host_tile_widths", _np_ptr(w), npart, height, width, _np_ptr(out))
+    return out
+
+
+class _Op(object):
+    """State shared by all ops: target device and re-used output buffers
+    (base_opt.hpp:12-72)."""
+
+    def __init__(self, device, timeit=False):
+        self.device_ = int(device)
+        self.timeit_ = bool(timeit)
+        self._top = {}
+        self._shape = None
+
+    def to(self, device):
+        device = int(device)
+        if device != self.device_:
+            self.device_ = device
+            self._top = {}
+            self._shape = None
+            self._moved()
+
+    def _moved(self):
+        pass
+
+    def _dev(self):
+        return torch.device("cuda", self.device_)
+
+    def _reshaped(self, shape):
+        shape = tuple(int(s) for s in shape)
+        if shape == self._shape:
+            return False
+        self._shape = shape
+        return True
+
+    def _out(self, slot, shape, like, zero=False):
+        """Op-owned output buffer, reallocated only when its shape changes."""
+        shape = tuple(int(s) for s in shape)
+        t = self._top.get(slot)
+        if t is None or tuple(t.shape) != shape or t.device != like.device:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=like.device)
+            self._top[slot] = t
+        return t
+
+    def _upload(self, array, like):
+        return torch.from_numpy(np.ascontiguousarray(array)).to(like.device)
+
+
+# ---------------------------------------------------------------------------
+# context objects
+# ---------------------------------------------------------------------------
+class _TileContext(_Op):
+    """Shared geometry cache: tile widths per tensor width and gather tables per
+    (height, width, pad).  Mirrors pseudo_context_opt / entropy_context
+    (pseudo_context.hpp:8-45, entropy_context.hpp:10-53)."""
+
+    def __init__(self, npart, rt, weight, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.npart_ = int(npart)
+        self.rt_ = int(rt)
+        self.weight_ = np.asarray(list(weight), dtype=np.float32)
+        if self.weight_.shape[0] != self.npart_:
+            raise PconvError("context: %d weights for %d tiles" % (self.weight_.shape[0], self.npart_))
+        self.data_width_ = -1
+        self._cache = {}
+        self._addr = "pconv-ctx-%x" % id(self)
+        _contexts[self._addr] = self
+
+    def addr(self):
+        return self._addr
+
+    def start_context(self, width):
+        if int(width) != self.data_width_:
+            self._cache = {}
+        self.data_width_ = int(width)
+
+    def _moved(self):
+        self._cache = {}
+
+    def widths_host(self, height, width):
+        key = ("wh", int(width))
+        if key not in self._cache:
+            self._cache[key] = tile_widths(self.weight_, self.npart_, int(height) * self.npart_, int(width))
+        return self._cache[key]
+
+    def widths(self, height, width, like):
+        key = ("wd", int(width), like.device)
+        if key not in self._cache:
+            self._cache[key] = self._upload(self.widths_host(height, width), like)
+        return self._cache[key]
+
+    def produce_fill_param(self, height, width):
+        dev = self._dev()
+        key = ("wd", int(width), dev)
+        if key not in self._cache:
+            self._cache[key] = torch.from_numpy(self.widths_host(height, width).copy()).to(dev)
+        return self._cache[key]
+
+
+class PseudoContextOp(_TileContext):
+    """PCONV.PseudoContextOp (main.cpp:90-95, pseudo_context_cuda.cu:12-48,140-167)."""
+
+    def pad_tables(self, height, width, pad, like):
+        key = ("pad", int(height), int(width), int(pad), like.device)
+        if key not in self._cache:
+            wh = self.widths_host(height, width)
+            n = self.npart_ * 2 * max(pad, 1)
+            src_tile = np.zeros(n, np.int32)
+            src_row = np.zeros(n, np.int32)
+            col = np.zeros(n * width, np.int32)
+            wgt = np.zeros(n * width, np.float32)
+            if pad > 0:
+                call("pconv_host_pad_table", _np_ptr(wh), self.npart_, height, width, pad,
+                     _np_ptr(src_tile), _np_ptr(src_row), _np_ptr(col), _np_ptr(wgt))
+            self._cache[key] = tuple(self._upload(a, like) for a in (src_tile, src_row, col, wgt))
+        return self._cache[key]
+
+
+class PseudoEntropyContextOp(_TileContext):
+    """PCONV.PseudoEntropyContextOp (main.cpp:109-113).  Only the geometry used by
+    PseudoFill (context_version 1) is provided; the whole-tensor causal pad of
+    the training-time EntropyNet is outside the codec hot path."""
+
+    def __init__(self, npart, rt, context_version, weight, device=0, timeit=False):
+        super().__init__(npart, rt, weight, device, timeit)
+        self.context_version_ = int(context_version)
+
+
+class EntropyContextOp(_TileContext):
+    """PCONV.EntropyContextOp (main.cpp:55-59, entropy_context_cuda.cu:13-222):
+    wavefront schedule + causal halo lists."""
+
+    def schedule(self, height, width, like):
+        key = ("sched", int(height), int(width), like.device)
+        if key not in self._cache:
+            wh = self.widths_host(height, width)
+            rows = height * self.npart_
+            order = np.zeros(rows * width, np.int32)
+            start = np.zeros(rows + width, np.int32)
+            call("pconv_host_wavefront", _np_ptr(wh), self.npart_, height, width, _np_ptr(order),
+                 _np_ptr(start))
+            self._cache[key] = (self._upload(order, like), start)
+        return self._cache[key]
+
+    def causal_halo(self, channel, height, width, pad, like):
+        key = ("halo", int(channel), int(height), int(width), int(pad), like.device)
+        if key not in self._cache:
+            wh = self.widths_host(height, width)
+            nplane = height * self.npart_ + width + pad - 1
+            start = np.zeros(nplane + 1, np.int32)
+            n = call("pconv_host_causal_halo", _np_ptr(wh), self.npart_, channel, height, width, pad,
+                     None, None, None, None, None, _np_ptr(start))
+            arrs = [np.zeros(max(n, 1), np.int32) for _ in range(3)]
+            wgt = np.zeros(max(n, 1), np.float32)
+            plane = np.zeros(max(n, 1), np.int32)
+            call("pconv_host_causal_halo", _np_ptr(wh), self.npart_, channel, height, width, pad,
+                 _np_ptr(arrs[0]), _np_ptr(arrs[1]), _np_ptr(arrs[2]), _np_ptr(wgt), _np_ptr(plane),
+                 _np_ptr(start))
+            dev = tuple(self._upload(a, like) for a in (arrs[0], arrs[1], arrs[2], wgt, plane))
+            self._cache[key] = (dev, start)
+        return self._cache[key]
+
+
+# ---------------------------------------------------------------------------
+# transform-path ops
+# ---------------------------------------------------------------------------
+class DtowOp(_Op):
+    """PCONV.DtowOp(stride, d2w, device, timeit) (main.cpp:12-16, dtow_cuda.cu:11-103)."""
+
+    def __init__(self, stride, d2w, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.stride_ = int(stride)
+        self.d2w_ = bool(d2w)
+
+    def forward(self, x):
+        _require_gpu(x, "DtowOp")
+        n, c, h, w = x.shape
+        s = self.stride_
+        shape = (n, c // (s * s), h * s, w * s) if self.d2w_ else (n, c * s * s, h // s, w // s)
+        out = self._out(0, shape, x)
+        call("pconv_dtow", _ptr(x), _ptr(out), n, c, h, w, s, int(self.d2w_), _stream(x.device))
+        return [out]
+
+    def backward(self, grad):
+        # the inverse permutation (dtow_cuda.cu:105-167)
+        _require_gpu(grad, "DtowOp.backward")
+        n, c, h, w = grad.shape
+        s = self.stride_
+        shape = (n, c * s * s, h // s, w // s) if self.d2w_ else (n, c // (s * s), h * s, w * s)
+        out = self._out(1, shape, grad)
+        call("pconv_dtow", _ptr(grad), _ptr(out), n, c, h, w, s, int(not self.d2w_), _stream(grad.device))
+        return [out]
+
+
+class ContextReshapeOp(_Op):
+    """PCONV.ContextReshapeOp(ngroup, device, timeit) (main.cpp:18-22)."""
+
+    def __init__(self, ngroup, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.ngroup_ = int(ngroup)
+
+    def forward(self, x):
+        _require_gpu(x, "ContextReshapeOp")
+        n, c, h, w = x.shape
+        out = self._out(0, (n * h * w * self.ngroup_, c // self.ngroup_), x)
+        call("pconv_context_reshape", _ptr(x), _ptr(out), n, c, h, w, self.ngroup_, _stream(x.device))
+        return [out]
+
+    def backward(self, grad):
+        raise NotImplementedError("ContextReshapeOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+class EntropyGmmOp(_Op):
+    """PCONV.EntropyGmmOp(num_gaussian, ignore_label, device, timeit) (main.cpp:24-28)."""
+
+    def __init__(self, num_gaussian, ignore_label, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.num_gaussian_ = int(num_gaussian)
+        self.ignore_label_ = int(ignore_label)
+
+    def forward(self, weight, delta, mean, label):
+        for t in (weight, delta, mean, label):
+            _require_gpu(t, "EntropyGmmOp")
+        m, ng = weight.shape[0], weight.shape[1]
+        if ng != self.num_gaussian_:
+            raise PconvError("EntropyGmmOp: last dim %d != num_gaussian %d" % (ng, self.num_gaussian_))
+        loss = self._out(0, (m,), weight)
+        dw = self._out(1, (m, ng), weight)
+        dd = self._out(2, (m, ng), weight)
+        dm = self._out(3, (m, ng), weight)
+        dl = self._out(4, (m, 1), weight)
+        call("pconv_gmm_loss", _ptr(weight), _ptr(delta), _ptr(mean), _ptr(label), _ptr(loss), _ptr(dw),
+             _ptr(dd), _ptr(dm), _ptr(dl), m, ng, _stream(weight.device))
+        return [loss]
+
+    def backward(self, grad):
+        raise NotImplementedError("EntropyGmmOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+class MaskConstrainOp(_Op):
+    """PCONV.MaskConstrainOp(constrain, ngroup, device, timeit) (main.cpp:30-34)."""
+
+    def __init__(self, constrain, ngroup, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.constrain_ = int(constrain)
+        self.ngroup_ = int(ngroup)
+
+    def forward(self, w):
+        _require_gpu(w, "MaskConstrainOp")
+        nout, cin, k, k2 = w.shape
+        call("pconv_mask_constrain", _ptr(w), nout, cin, k, self.ngroup_, self.constrain_, _stream(w.device))
+
+    def backward(self, grad):
+        self.forward(grad)
+
+
+class _SphereResample(_Op):
+    def __init__(self, npart, interp_type, pad, weight, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.npart_ = int(npart)
+        self.interp_type_ = int(interp_type)
+        self.pad_ = int(pad)
+        self.weight_ = np.asarray(list(weight), dtype=np.float32)
+        self._tabs = {}
+
+    def _moved(self):
+        self._tabs = {}
+
+    def _tables(self, builder, height, width, like):
+        key = (int(height), int(width), like.device)
+        if key not in self._tabs:
+            wh = tile_widths(self.weight_, self.npart_, height, width)
+            col = np.zeros(self.npart_ * width, np.int32)
+            coef = np.zeros(self.npart_ * width * 4, np.float32)
+            call(builder, _np_ptr(wh), self.npart_, width, _np_ptr(col), _np_ptr(coef))
+            self._tabs[key] = tuple(self._upload(a, like) for a in (wh, col, coef))
+        return self._tabs[key]
+
+
+class SphereSliceOp(_SphereResample):
+    """PCONV.SphereSliceOp(npart, interp, pad, weight, device, timeit)
+    (main.cpp:37-41, sphere_slice_cuda.cu:55-146)."""
+
+    def forward(self, x):
+        _require_gpu(x, "SphereSliceOp")
+        n, c, h, w = x.shape
+        if h % self.npart_:
+            raise PconvError("SphereSliceOp: height %d is not a multiple of npart %d" % (h, self.npart_))
+        wd, col, coef = self._tables("pconv_host_slice_taps", h, w, x)
+        p = self.pad_
+        out = self._out(0, (n * self.npart_, c, h // self.npart_ + 2 * p, w + 2 * p), x, zero=p > 0)
+        call("pconv_sphere_slice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+             self.npart_, p, _stream(x.device))
+        return [out]
+
+    def backward(self, grad):
+        raise NotImplementedError("SphereSliceOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+class SphereUsliceOp(_SphereResample):
+    """PCONV.SphereUsliceOp (main.cpp:43-47, sphere_uslice_cuda.cu:32-126)."""
+
+    def forward(self, x):
+        _require_gpu(x, "SphereUsliceOp")
+        p = self.pad_
+        tn, c, hp, wp = x.shape
+        h, w = hp - 2 * p, wp - 2 * p
+        if tn % self.npart_:
+            raise PconvError("SphereUsliceOp: batch %d is not a multiple of npart %d" % (tn, self.npart_))
+        n = tn // self.npart_
+        wd, col, coef = self._tables("pconv_host_uslice_taps", h * self.npart_, w, x)
+        out = self._out(0, (n, c, h * self.npart_, w), x)
+        call("pconv_sphere_uslice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+             self.npart_, p, _stream(x.device))
+        return [out]
+
+    def backward(self, grad):
+        raise NotImplementedError("SphereUsliceOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+class PseudoPadOp(_Op):
+    """PCONV.PseudoPadOp(pad, npart, ctx_addr, device, timeit)
+    (main.cpp:97-101, pseudo_pad.cu:12-125); one fused launch."""
+
+    def __init__(self, pad, npart, ctx_addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.pad_ = int(pad)
+        self.npart_ = int(npart)
+        self.ctx_ = _lookup(ctx_addr)
+
+    def forward(self, x):
+        _require_gpu(x, "PseudoPadOp")
+        tn, c, h, w = x.shape
+        p = self.pad_
+        wd = self.ctx_.widths(h, w, x)
+        st, sr, col, wgt = self.ctx_.pad_tables(h, w, p, x)
+        out = self._out(0, (tn, c, h + 2 * p, w + 2 * p), x)
+        call("pconv_pseudo_pad", _ptr(x), _ptr(out), _ptr(wd), _ptr(st), _ptr(sr), _ptr(col), _ptr(wgt), tn,
+             c, h, w, p, self.npart_, _stream(x.device))
+        return [out]
+
+    def backward(self, grad):
+        raise NotImplementedError("PseudoPadOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+class PseudoFillOp(_Op):
+    """PCONV.PseudoFillOp(pad, npart, fvalue, trim, addr, context_version, device, timeit)
+    (main.cpp:103-107, pseudo_fill_cuda.cu:11-77); in place."""
+
+    def __init__(self, pad, npart, fvalue, trim, addr, context_version, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.pad_, self.npart_ = int(pad), int(npart)
+        self.fvalue_, self.trim_ = int(fvalue), int(trim)
+        self.context_version_ = int(context_version)
+        self.ctx_ = _lookup(addr)
+
+    def _run(self, x, value):
+        _require_gpu(x, "PseudoFillOp")
+        tn, c, h, w = x.shape
+        wd = self.ctx_.widths(h, w, x)
+        call("pconv_pseudo_fill", _ptr(x), _ptr(wd), tn, c, h, w, self.npart_, self.pad_, self.trim_,
+             float(value), _stream(x.device))
+        return [x]
+
+    def forward(self, x):
+        return self._run(x, self.fvalue_)
+
+    def backward(self, grad):
+        return self._run(grad, 0.0)
+
+
+class PseudoEntropyPadOp(_Op):
+    """PCONV.PseudoEntropyPadOp (main.cpp:115-119).  Training-only op of the
+    reference's EntropyNet; declared so the module surface is complete."""
+
+    def __init__(self, pad, npart, addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.pad_, self.npart_ = int(pad), int(npart)
+        self.ctx_ = _lookup(addr)
+
+    def forward(self, x):
+        raise NotImplementedError(
+            "PseudoEntropyPadOp.forward: whole-tensor causal pad of the training-time EntropyNet "
+            "is outside the codec hot path (SURVEY 2.1, 8f-4)")
+
+    backward = forward
+
+
+class PseudoQuantOp(_Op):
+    """PCONV.PseudoQuantOp(channel, bins, npart, decay, check_iters, ntop, top_alpha, addr,
+    device, timeit) (main.cpp:121-125, pseudo_quant_cuda.cu:157-194); eval forward."""
+
+    def __init__(self, channel, bin_num, npart, weight_decay, check_iters, ntop, top_alpha, addr,
+                 device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.channel_, self.bin_num_, self.npart_ = int(channel), int(bin_num), int(npart)
+        self.ntop_ = int(ntop)
+        self.weight_decay_, self.mod_ = float(weight_decay), int(check_iters)
+        self.iter_ = 0
+        self.ctx_ = _lookup(addr)
+
+    def update_weight(self, weight, ncount):
+        """Every `check_iters` training-mode calls: merge quantiser levels that the
+        running histogram `ncount` says are unused, then decay the histogram
+        (pseudo_quant_cuda.cu:97-143).  The reference's codec driver never calls
+        .eval(), so this path is live there too (pseudo_codec.py:241-246)."""
+        if self.iter_ % self.mod_ != 0 or self.iter_ == 0:
+            return
+        levels = self.bin_num_
+        w, cnt = weight.data, ncount.data
+        used = cnt >= 1e-3
+        idx = torch.arange(levels, device=w.device).expand_as(w)
+        top = torch.where(used & (idx >= 2), idx, torch.ones_like(idx)).max(dim=1).values  # last used level, >= 1
+        base = w.gather(1, top[:, None])[:, 0] - torch.log((levels - top).to(w.dtype))
+        w.copy_(torch.where(idx >= top[:, None], base[:, None].expand_as(w), w))
+        empty0 = cnt[:, 0] < 1e-3
+        if bool(empty0.any()):
+            w0 = w[:, 0] + torch.exp(w[:, 1])
+            merged = torch.log((torch.exp(w[:, 1]) + torch.exp(w[:, 2])) / 2)
+            w[:, 0] = torch.where(empty0, w0, w[:, 0])
+            w[:, 1] = torch.where(empty0, merged, w[:, 1])
+            w[:, 2] = torch.where(empty0, merged, w[:, 2])
+        cnt.mul_(self.weight_decay_)
+
+    def forward(self, x, weight, count, train):
+        _require_gpu(x, "PseudoQuantOp")
+        if train:
+            self.update_weight(weight, count)
+        tn, c, h, w = x.shape
+        if c != self.channel_ or tuple(weight.shape) != (c, self.bin_num_):
+            raise PconvError("PseudoQuantOp: channel/level mismatch")
+        wd = self.ctx_.widths(h, w, x)
+        tab = self._out("tab", (c, self.bin_num_), x)
+        val = self._out(0, x.shape, x)
+        idx = self._out(1, x.shape, x) if self.ntop_ > 1 else None
+        call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), None, _ptr(wd),
+             tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
+        if train:
+            self.iter_ += 1
+        return [val, idx] if idx is not None else [val]
+
+    def backward(self, grads, x, out):
+        raise NotImplementedError("PseudoQuantOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+class PseudoDQuantOp(_Op):
+    """PCONV.PseudoDQuantOp(npart, channel, bins, addr, device, timeit)
+    (main.cpp:127-130, pseudo_dquant_cuda.cu:11-70)."""
+
+    def __init__(self, npart, channel, bin_num, addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.npart_, self.nchannel_, self.bin_num_ = int(npart), int(channel), int(bin_num)
+        self.ctx_ = _lookup(addr)
+
+    def forward(self, x, weight):
+        _require_gpu(x, "PseudoDQuantOp")
+        tn, c, h, w = x.shape
+        if tuple(weight.shape) != (self.nchannel_, self.bin_num_):
+            raise PconvError("PseudoDQuantOp: weight shape %s != (%d, %d)" %
+                             (tuple(weight.shape), self.nchannel_, self.bin_num_))
+        wd = self.ctx_.widths(h, w, x)
+        tab = self._out("tab", (self.nchannel_, self.bin_num_), x)
+        out = self._out(0, x.shape, x)
+        call("pconv_dquant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(out), _ptr(wd), tn, c, h, w,
+             self.nchannel_, self.bin_num_, self.npart_, _stream(x.device))
+        return [out]
+
+
+class ProjectsOp(_Op):
+    """PCONV.ProjectsOp(h, w, thetas, phis, fov, near, device, timeit)
+    (main.cpp:6-10, projects_cuda.cu:98-255)."""
+
+    def __init__(self, h_out, w_out, thetas, phis, fov=0.33333, near=False, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.h_out_, self.w_out_ = int(h_out), int(w_out)
+        self.theta_ = np.asarray(list(thetas), np.float32)
+        self.phi_ = np.asarray(list(phis), np.float32)
+        if self.theta_.shape != self.phi_.shape:
+            raise PconvError("ProjectsOp: thetas and phis differ in length")
+        self.nview_ = int(self.theta_.shape[0])
+        self.fov_, self.near_ = float(fov), bool(near)
+        self._tf = {}
+
+    def _moved(self):
+        self._tf = {}
+
+    def forward(self, x):
+        _require_gpu(x, "ProjectsOp")
+        n, c, h, w = x.shape
+        key = (h, w, x.device)
+        if key not in self._tf:
+            tf = np.zeros(self.nview_ * self.h_out_ * self.w_out_ * 2, np.float32)
+            call("pconv_host_project_table", _np_ptr(self.theta_), _np_ptr(self.phi_), self.nview_, self.fov_,
+                 self.h_out_, self.w_out_, h, w, _np_ptr(tf))
+            self._tf[key] = self._upload(tf, x)
+        out = self._out(0, (n * self.nview_, c, self.h_out_, self.w_out_), x)
+        call("pconv_project", _ptr(x), _ptr(self._tf[key]), _ptr(out), n, c, h, w, self.nview_, self.h_out_,
+             self.w_out_, int(self.near_), _stream(x.device))
+        return [out]
+
+    def backward(self, grad):
+        raise NotImplementedError("ProjectsOp.backward: training path is out of scope (SURVEY 2.1)")
+
+
+# ---------------------------------------------------------------------------
+# entropy wavefront ops
+# ---------------------------------------------------------------------------
+class _WavefrontOp(_Op):
+    """Step counter shared by the entropy ops: `pidx_` advances on every forward,
+    is reset by restart() or a shape change (e.g. d_input_v2.hpp:21,
+    d_input_cuda_v2.cu:16)."""
+
+    def __init__(self, device, timeit):
+        super().__init__(device, timeit)
+        self.pidx_ = 0
+
+    def restart(self):
+        self.pidx_ = 0
+
+    def _step(self):
+        p = self.pidx_
+        self.pidx_ += 1
+        return p
+
+    @staticmethod
+    def _window(psum, ngroup, last_plane, start):
+        """Schedule slice of a step: planes [psum-ngroup+1, psum] clipped to
+        [0, last_plane]; returns (lo, len)."""
+        st = max(psum - ngroup + 1, 0)
+        end = psum + 1 if psum < last_plane else last_plane + 1
+        if st >= len(start) or end >= len(start) or st > end:
+            return 0, 0
+        return int(start[st]), int(start[end] - start[st])
+
+
+class DInput2Op(_WavefrontOp):
+    """PCONV.DInput2Op(nchannel, npart, pad, bias, repeat, addr, device, timeit)
+    (main.cpp:75-79, d_input_cuda_v2.cu:13-86)."""
+
+    def __init__(self, nchannel, npart, pad, bias, repeat, addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.channel_, self.npart_, self.pad_ = int(nchannel), int(npart), int(pad)
+        self.bias_, self.rep_ = float(bias), int(repeat)
+        self.ctx_ = _lookup(addr)
+
+    def forward(self, x):
+        _require_gpu(x, "DInput2Op")
+        nimg, h, w = x.shape[0], x.shape[2] // self.npart_, x.shape[3]
+        if self._reshaped((nimg, h, w)):
+            self.pidx_ = 0
+        order, start = self.ctx_.schedule(h, w, x)
+        p = self.pad_
+        top = self._out(0, (self.rep_ * nimg * self.npart_, self.channel_, h + 2 * p, w + 2 * p), x)
+        psum = self._step()
+        rows = h * self.npart_
+        if psum == 0:
+            top.zero_()
+        elif psum <= rows + w + self.channel_ - 2:
+            psum -= 1
+            lo, ln = self._window(psum, self.channel_, rows + w - 2, start)
+            if ln > 0:
+                call("pconv_dinput2", _ptr(x), _ptr(top), _ptr(order), lo, ln, nimg, self.channel_,
+                     self.npart_, h, w, p, psum, self.bias_, self.rep_, _stream(x.device))
+        return [top]
+
+
+class EntropyCtxPadRun2Op(_WavefrontOp):
+    """PCONV.EntropyCtxPadRun2Op(pad, npart, ngroup, input, ctx_addr, device, timeit)
+    (main.cpp:61-66, entropy_ctx_pad_run2_cuda.cu:11-117); in place."""
+
+    def __init__(self, pad, npart, ngroup, input, ctx_addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.pad_, self.npart_, self.ngroup_ = int(pad), int(npart), int(ngroup)
+        self.input_ = bool(input)
+        self.ctx_ = _lookup(ctx_addr)
+
+    def forward(self, x):
+        _require_gpu(x, "EntropyCtxPadRun2Op")
+        p = self.pad_
+        num, channel, h, w = x.shape[0], x.shape[1], x.shape[2] - 2 * p, x.shape[3] - 2 * p
+        if self._reshaped((num, channel, h, w)):
+            self.pidx_ = 0
+        (dst, s0, s1, wgt, plane), start = self.ctx_.causal_halo(channel, h, w, p, x)
+        psum = self._step()
+        if self.input_:
+            psum -= 1
+        rows = h * self.npart_
+        if 0 <= psum < rows + w + p + self.ngroup_ - 2:
+            lo, ln = self._window(psum, self.ngroup_, rows + w + p - 2, start)
+            if ln > 0:
+                call("pconv_ctx_pad_run2", _ptr(x), _ptr(dst), _ptr(s0), _ptr(s1), _ptr(wgt), _ptr(plane), lo,
+                     ln, num // self.npart_, channel // self.ngroup_, channel, self.npart_, h, w, p, psum,
+                     _stream(x.device))
+        return [x]
+
+    def backward(self, grad):
+        return []
+
+
+class EntropyConv2Op(_WavefrontOp):
+    """PCONV.EntropyConv2Op(npart, channel, ngroup, nout, k, constrain, pad_in, pad_out, addr,
+    device, timeit) (main.cpp:81-88, entropy_conv_cuda_v2.cu:11-459)."""
+
+    def __init__(self, npart, channel, ngroup, nout, kernel_size, constrain, pad_in, pad_out, addr,
+                 device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.npart_, self.channel_, self.ngroup_, self.nout_ = int(npart), int(channel), int(ngroup), int(nout)
+        self.kernel_size_, self.constrain_ = int(kernel_size), int(constrain)
+        self.pad_in_, self.pad_out_ = int(pad_in), int(pad_out)
+        self.ctx_ = _lookup(addr)
+
+    def _run(self, x, weight, bias, act, nset):
+        _require_gpu(x, "EntropyConv2Op")
+        pi, po = self.pad_in_, self.pad_out_
+        num, channel, h, w = x.shape[0], x.shape[1], x.shape[2] - 2 * pi, x.shape[3] - 2 * pi
+        if channel != self.channel_:
+            raise PconvError("EntropyConv2Op: %d input channels, built for %d" % (channel, self.channel_))
+        if self._reshaped((num, channel, h, w)):
+            self.pidx_ = 0
+        order, start = self.ctx_.schedule(h, w, x)
+        top = self._out(0, (num, self.nout_, h + 2 * po, w + 2 * po), x)
+        psum = self._step()
+        rows = h * self.npart_
+        nimg = num // self.npart_
+        if psum < rows + w + self.ngroup_ - 2:
+            lo, ln = self._window(psum, self.ngroup_, rows + w - 2, start)
+            if ln > 0:
+                if psum == 0:
+                    top.zero_()
+                call("pconv_entropy_conv", _ptr(x), _ptr(weight.detach()), _ptr(bias.detach()),
+                     _ptr(act.detach()) if act is not None else None, _ptr(top), _ptr(order), lo, ln, nimg,
+                     max(nimg // nset, 1), channel, self.nout_, self.ngroup_, self.kernel_size_,
+                     self.constrain_, self.npart_, h, w, pi, po, psum, _stream(x.device))
+        return [top]
+
+    def forward(self, x, weight, bias):
+        return self._run(x, weight, bias, None, 1)
+
+    def forward_act(self, x, weight, bias, act):
+        return self._run(x, weight, bias, act, 1)
+
+    def forward_batch(self, x, weight, bias):
+        return self._run(x, weight, bias, None, int(weight.shape[0]))
+
+    def forward_act_batch(self, x, weight, bias, act):
+        return self._run(x, weight, bias, act, int(weight.shape[0]))
+
+
+class EntropyAddOp(_WavefrontOp):
+    """PCONV.EntropyAddOp(npart, channel, ngroup, pad, addr, device, timeit)
+    (main.cpp:132-136, entropy_add_cuda.cu:11-75); x += y in place."""
+
+    def __init__(self, npart, channel, ngroup, pad, addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.npart_, self.channel_, self.ngroup_, self.pad_ = int(npart), int(channel), int(ngroup), int(pad)
+        self.ctx_ = _lookup(addr)
+
+    def forward(self, x, y):
+        _require_gpu(x, "EntropyAddOp")
+        _require_gpu(y, "EntropyAddOp")
+        p = self.pad_
+        num, channel, h, w = x.shape[0], x.shape[1], x.shape[2] - 2 * p, x.shape[3] - 2 * p
+        if self._reshaped((num, channel, h, w)):
+            self.pidx_ = 0
+        order, start = self.ctx_.schedule(h, w, x)
+        psum = self._step()
+        rows = h * self.npart_
+        if psum <= rows + w + self.ngroup_ - 2:
+            lo, ln = self._window(psum, self.ngroup_, rows + w - 2, start)
+            if ln > 0:
+                call("pconv_entropy_add", _ptr(x), _ptr(y), _ptr(order), lo, ln, num // self.npart_,
+                     self.channel_, self.ngroup_, self.npart_, h, w, p, psum, _stream(x.device))
+        return [x]
+
+
+class DExtract2Op(_WavefrontOp):
+    """PCONV.DExtract2Op(npart, nchannel, label, addr, device, timeit)
+    (main.cpp:68-73, d_extract_cuda_v2.cu:12-166)."""
+
+    def __init__(self, npart, nchannel, label, addr, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.npart_, self.nchannel_, self.label_ = int(npart), int(nchannel), bool(label)
+        self.ctx_ = _lookup(addr)
+        self.top_num_ = torch.zeros(1, dtype=torch.int32)
+
+    def _prepare(self, x):
+        _require_gpu(x, "DExtract2Op")
+        num, channel, h, w = x.shape
+        if self._reshaped((num, channel, h, w)):
+            self.pidx_ = 0
+            self.top_num_ = torch.zeros(1, dtype=torch.int32)
+        order, start = self.ctx_.schedule(h, w, x)
+        cpn = channel // self.nchannel_
+        top = self._out(0, (num // self.npart_, cpn, h * self.npart_, w), x)
+        return num, channel, h, w, cpn, order, start, top
+
+    def forward(self, x):
+        num, channel, h, w, cpn, order, start, top = self._prepare(x)
+        psum = self._step()
+        rows = h * self.npart_
+        mod = rows + w + self.nchannel_ - 2
+        nimg = num // self.npart_
+        run = False
+        if self.label_:
+            run = psum < mod
+        elif psum == 0:
+            top.zero_()
+        elif psum <= mod:
+            psum -= 1
+            run = True
+        if run:
+            lo, ln = self._window(psum, self.nchannel_, rows + w - 2, start)
+            self.top_num_[0] = ln * nimg
+            if ln > 0:
+                call("pconv_dextract2", _ptr(x), _ptr(top), _ptr(order), lo, ln, nimg, channel, cpn,
+                     self.npart_, h, w, psum, _stream(x.device))
+        return [top, self.top_num_]
+
+    def forward_batch(self, x):
+        num, channel, h, w, cpn, order, start, top = self._prepare(x)
+        psum = self._step()
+        rows = h * self.npart_
+        nimg = num // self.npart_
+        nout = nimg // 3
+        if psum < rows + w + self.nchannel_ - 2:
+            lo, ln = self._window(psum, self.nchannel_, rows + w - 2, start)
+            self.top_num_[0] = nout * ln
+            if ln > 0:
+                call("pconv_dextract2_batch", _ptr(x), _ptr(top), _ptr(order), lo, ln, nimg, channel, cpn,
+                     self.npart_, h, w, psum, nout, cpn * rows * w * nout, _stream(x.device))
+        return [top, self.top_num_]
+
+
+class EntropyGmmTableOp(_Op):
+    """PCONV.EntropyGmmTableOp(nstep, bias, K, total, beta, device, timeit)
+    (main.cpp:49-53, entropy_gmm_table_cuda.cu:11-185)."""
+
+    def __init__(self, nstep, bias, num_gaussian, total_region, beta=1e-6, device=0, timeit=False):
+        super().__init__(device, timeit)
+        self.nstep_, self.bias_ = int(nstep), float(bias)
+        self.num_gaussian_, self.total_region_, self.beta_ = int(num_gaussian), float(total_region), float(beta)
+        if self.num_gaussian_ > 16:
+            raise PconvError("EntropyGmmTableOp: at most 16 gaussians")
+
+    def forward(self, weight, delta, mean, tnum):
+        for t in (weight, delta, mean):
+            _require_gpu(t, "EntropyGmmTableOp")
+        rows = weight.numel() // self.num_gaussian_
+        if weight.dim() == 4:
+            rows = weight.shape[0] * weight.shape[2] * weight.shape[3]
+        table = self._out(0, (rows, self.nstep_ + 1), weight)
+        tn = int(tnum[0])
+        call("pconv_gmm_table", _ptr(weight), _ptr(delta), _ptr(mean), _ptr(table), tn, self.num_gaussian_,
+             self.nstep_, self.bias_, self.total_region_, self.beta_, 0, _stream(weight.device))
+        return [table]
+
+    def forward_batch(self, data, tnum):
+        _require_gpu(data, "EntropyGmmTableOp")
+        stride = data.numel() // 3
+        table = self._out(0, (data.shape[0] * data.shape[2] * data.shape[3] // 3, self.nstep_ + 1), data)
+        tn = int(tnum[0])
+        if tn > 0:
+            base = data.data_ptr()
+            call("pconv_gmm_table", base, base + 4 * stride, base + 8 * stride, _ptr(table), tn,
+                 self.num_gaussian_, self.nstep_, self.bias_, self.total_region_, self.beta_, 1,
+                 _stream(data.device))
+        return [table]
+
+
+# ---------------------------------------------------------------------------
+# dense tile convolution (not a class of the reference's PCONV: it replaces the
+# cuDNN calls behind nn.Conv2d in model_zoo_v2.py)
+# ---------------------------------------------------------------------------
+def packed_conv_weight(owner, weight, stream):
+    """[k][cout] fp32 slab of a conv weight for pconv_conv2d, cached on `owner`
+    until the parameter is modified."""
+    key = (weight.data_ptr(), weight._version, weight.device)
+    cached = getattr(owner, "_pconv_packed", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    cout, cin, k, k2 = weight.shape
+    size = _native.hip_lib().pconv_conv_packed_size(cout, cin, k, None, None)
+    packed = torch.empty(size, dtype=torch.float32, device=weight.device)
+    call("pconv_conv_pack_weight", _ptr(weight.detach().contiguous()), _ptr(packed), cout, cin, k, stream)
+    owner._pconv_packed = (key, packed)
+    return packed
+
+
+def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0):
+    """y = conv2d(x, weight, bias, stride) (+ PReLU(slope)), no padding, on the
+    fp32 matrix cores.  x (tn, cin, h, w) -> (tn, cout, ho, wo)."""
+    _require_gpu(x, "tile_conv2d")
+    tn, cin, h, w = x.shape
+    cout, cin_w, k, k2 = weight.shape
+    if cin != cin_w or k != k2:
+        raise PconvError("tile_conv2d: weight %s does not fit input %s" % (tuple(weight.shape), tuple(x.shape)))
+    stream = _stream(x.device)
+    packed = packed_conv_weight(owner, weight, stream)
+    ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
+    out = torch.empty((tn, cout, ho, wo), dtype=torch.float32, device=x.device)
+    call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
+         tn, cin, h, w, cout, k, int(stride), 1 if slope is not None else 0,
+         _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart), stream)
+    return out

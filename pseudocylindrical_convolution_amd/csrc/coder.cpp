@@ -198,8 +198,10 @@ struct pconv_coder {
 
 template <typename T>
 static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, int n) {
-  if (!c || !table || !out || ncode <= 0) return PCONV_CODER_EARG;
+  if (!c || ncode <= 0) return PCONV_CODER_EARG;
   if (c->mode != pconv_coder::DECODING) return c->fail(PCONV_CODER_ESTATE, "decoder not started");
+  if (n <= 0) return 0;
+  if (!table || !out) return c->fail(PCONV_CODER_EARG, "null table or output");
   const int stride = ncode + 1;
   for (int i = 0; i < n; i++) {
     const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
@@ -251,8 +253,10 @@ int pconv_coder_encode(pconv_coder *c, const uint32_t *table, uint32_t ncode, ui
 
 int pconv_coder_encodes(pconv_coder *c, const int32_t *table, int ncode, const int32_t *symbols,
                         int n) {
-  if (!c || !table || !symbols || ncode <= 0) return PCONV_CODER_EARG;
+  if (!c || ncode <= 0) return PCONV_CODER_EARG;
   if (c->mode != pconv_coder::ENCODING) return c->fail(PCONV_CODER_ESTATE, "encoder not started");
+  if (n <= 0) return 0;
+  if (!table || !symbols) return c->fail(PCONV_CODER_EARG, "null table or symbols");
   const int stride = ncode + 1;
   for (int i = 0; i < n; i++) {
     const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);

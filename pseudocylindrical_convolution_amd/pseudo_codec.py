@@ -1,0 +1,389 @@
+"""360-degree image codec driver (reference: pseudo_codec.py:27-356).
+
+Inference-time entropy model (EntEncoder / EntDecoder wavefront loops), the
+end-to-end PseudoEncoder / PseudoDecoder, evaluation and the command line.
+Differences from the reference, all additive:
+  * any ERP size with height % 256 == 0 and width % 16 == 0 (the reference
+    hard-codes 512x1024 latents, pseudo_codec.py:206,209,229-234); the defaults
+    reproduce the reference exactly;
+  * images are read/written with PIL (cv2 is not required) in the reference's BGR
+    channel order, so its checkpoints stay valid.
+Module / parameter names are the reference's, so `{idx}_encoder.pt`,
+`{idx}_decoder.pt` and `{idx}_ent.pt` load with strict=True (pseudo_codec.py:223-227).
+"""
+import argparse
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from .PCONV_operator import (DExtract2, DExtract2Batch, DInput2, Dtow, EntropyAdd, EntropyBatchGmmTable,
+                             EntropyContextNew, EntropyConv2Batch, EntropyCtxPadRun2, Extract, MultiProject,
+                             PseudoContextV2, PseudoDQUANT, PseudoFillV2, PseudoQUANTV2, SphereSlice,
+                             SphereUslice, SSIM, backend)
+from .model_zoo_v2 import ClipData, DecoderV2, EncoderV2
+
+psnr_f = lambda xa: 10 * math.log10(1. / xa)
+
+model_ssim_list = ['1_56', '2_56', '3_56', '4_56', '5_112', '6_112', '7_112', '8_192', '9_192']
+ssim_channel_list = [56, 56, 56, 56, 112, 112, 112, 192, 192]
+model_mse_list = ['1_56', '2_56', '3_56', '4_112', '5_112', '6_112', '7_112', '8_192', '9_192', '10_192']
+mse_channel_list = [56, 56, 56, 112, 112, 112, 112, 192, 192, 192]
+mse_model_dir = './demo/mse'
+ssim_model_dir = './demo/ssim'
+
+NPART = 16          # latitude tiles (pseudo_codec.py:166)
+CHANNELS = 192      # transform width and code channels
+QUANT_LEVELS = 8
+DOWN = 16           # spatial down-sampling of the analysis transform
+
+
+def latent_shape(height, width, npart=NPART):
+    """(rows per tile, columns) of the code tensor for an ERP of height x width."""
+    if height % (npart * DOWN) or width % DOWN:
+        raise ValueError('ERP size %dx%d: height must be a multiple of %d and width of %d'
+                         % (height, width, npart * DOWN, DOWN))
+    return height // npart // DOWN, width // DOWN
+
+
+class EntropyConvDBT(nn.Module):
+    """causal halo update + masked conv with three weight sets (reference: pseudo_codec.py:27-38)."""
+
+    def __init__(self, batch, ngroups, cin, cout, hidden, npart, out_layer, ctx, device_id, act=True):
+        super(EntropyConvDBT, self).__init__()
+        self.pad = EntropyCtxPadRun2(2, npart, ngroups, ctx, not hidden, device=device_id)
+        self.conv = EntropyConv2Batch(npart, ngroups, cin, cout, 5, ctx, 2, 0 if out_layer else 2, batch=batch,
+                                      hidden=hidden, act=act, device=device_id)
+
+    def forward(self, x):
+        return self.conv(self.pad(x))
+
+
+class EntropyResidualBlockDBT(nn.Module):
+    """(reference: pseudo_codec.py:40-51)"""
+
+    def __init__(self, batch, ngroups, cpn, npart, ctx, device_id=0):
+        super(EntropyResidualBlockDBT, self).__init__()
+        self.conv1 = EntropyConvDBT(batch, ngroups, cpn, cpn, True, npart, False, ctx, device_id, True)
+        self.conv2 = EntropyConvDBT(batch, ngroups, cpn, cpn, True, npart, False, ctx, device_id, True)
+        self.add = EntropyAdd(npart, cpn * ngroups, ngroups, 2, ctx, device=device_id)
+
+    def forward(self, x):
+        return self.add(self.conv2(self.conv1(x)), x)
+
+
+_STEPPED = (EntropyConv2Batch, EntropyCtxPadRun2, EntropyAdd, DInput2, DExtract2, DExtract2Batch)
+
+
+@torch.no_grad()
+def restart_entropy_network(m):
+    """reset the step counter of every wavefront op (reference: pseudo_codec.py:53-66)"""
+    if isinstance(m, _STEPPED):
+        m.restart()
+
+
+class _EntropyModel(nn.Module):
+    """what the encoder and decoder sides share: context, input scatter, the
+    12-layer three-headed masked network, GMM table"""
+
+    def __init__(self, ngroup, npart, opt_f, bin_num, gid):
+        super(_EntropyModel, self).__init__()
+        self.cuda = backend.device_of(gid)
+        self.ctx2 = EntropyContextNew(npart, opt=opt_f, device=gid)
+        self.ipt = DInput2(ngroup, npart, self.ctx2, 2, -3.5, 3, device=gid)
+        self.npart, self.ngroup = npart, ngroup
+        self.fill = PseudoFillV2(0, npart, self.ctx2, 0, device=gid)
+        self.mcoder = None
+        self.bias = (bin_num - 1) / 2.
+        layers = [EntropyConvDBT(3, ngroup, 1, 3, False, npart, False, self.ctx2, gid, True)]
+        layers += [EntropyResidualBlockDBT(3, ngroup, 3, npart, self.ctx2, gid) for _ in range(5)]
+        layers += [EntropyConvDBT(3, ngroup, 3, 3, True, npart, True, self.ctx2, gid, False)]
+        self.net = nn.Sequential(*layers)
+        self.ext = DExtract2Batch(npart, ngroup, self.ctx2, device=gid)
+        self.gmm = EntropyBatchGmmTable(bin_num, self.bias, 3, 65536, device=gid)
+
+    def start(self, code_name='./tmp/data'):
+        self.apply(restart_entropy_network)
+        self.mcoder = backend.coder().coder(code_name)
+
+    def steps(self, h_full, w):
+        return h_full + w + self.ngroup - 2
+
+    def tables(self, packed):
+        """one wavefront step: scatter `packed` symbols of the previous step, run
+        the network, return (integer CDF rows on the CPU, number of rows)"""
+        b = self.ipt(packed)
+        z, le = self.ext(self.net(b))
+        vec = self.gmm(z, le)
+        return b, vec.type(torch.int32).to('cpu'), int(le[0].item())
+
+
+class EntEncoder(_EntropyModel):
+    """(reference: pseudo_codec.py:68-114)"""
+
+    def __init__(self, ngroup, npart=16, opt_f=True, bin_num=8, gid=0):
+        super(EntEncoder, self).__init__(ngroup, npart, opt_f, bin_num, gid)
+        self.ext_label = DExtract2(npart, ngroup, True, self.ctx2, device=gid)
+        self.net = self.net.to(self.cuda)
+
+    def forward(self, data):
+        with torch.no_grad():
+            data = self.fill(data)
+            h, w = data.shape[2:]
+            self.ctx2.setup_context(w)
+            self.mcoder.start_encoder()
+            h_full = h * self.npart
+            label = torch.zeros((1, 1, h_full, w), dtype=torch.float32).to(self.cuda)
+            for _ in range(self.steps(h_full, w)):
+                _, pred, ln = self.tables(label)
+                label, _ = self.ext_label(data)
+                self.mcoder.encodes(pred, 8, label.type(torch.int32).to('cpu'), ln)
+            self.mcoder.end_encoder()
+
+
+class EntDecoder(_EntropyModel):
+    """(reference: pseudo_codec.py:117-160)"""
+
+    def __init__(self, ngroup, npart=16, opt_f=True, bin_num=8, gid=0):
+        super(EntDecoder, self).__init__(ngroup, npart, opt_f, bin_num, gid)
+        self.net = self.net.to(self.cuda)
+
+    def forward(self, h, w):
+        with torch.no_grad():
+            self.ctx2.setup_context(w)
+            self.mcoder.start_decoder()
+            h_full = h * self.npart
+            pout = torch.zeros((1, 1, h_full, w), dtype=torch.float32).to(self.cuda)
+            b = None
+            for _ in range(self.steps(h_full, w)):
+                b, pred, ln = self.tables(pout)
+                pout = self.mcoder.decodes(pred.view(-1, 9), 8, ln).to(self.cuda).view(1, 1, h_full, w).contiguous()
+            code = (b[:self.npart, :, 2:-2, 2:-2] + self.bias).contiguous()
+            return self.fill(code)
+
+
+class PseudoEncoder(nn.Module):
+    """ERP image -> code file (reference: pseudo_codec.py:162-186)"""
+
+    def __init__(self, valid_dim, device_id):
+        super(PseudoEncoder, self).__init__()
+        npart, opt = NPART, True
+        dev = backend.device_of(device_id)
+        self.slice = SphereSlice(npart, pad=0, opt=opt, device=device_id)
+        self.ctx = PseudoContextV2(npart, opt, device=device_id)
+        self.encoder = EncoderV2(CHANNELS, CHANNELS, npart, self.ctx, device_id).to(dev)
+        self.quant = PseudoQUANTV2(CHANNELS, QUANT_LEVELS, npart, self.ctx, device_id=device_id, ntop=2)
+        self.ext = Extract(valid_dim)
+        self.mean_val = (QUANT_LEVELS - 1) / 2.
+        self.dtw = Dtow(2, True, device_id)
+        self.ent = EntEncoder(valid_dim // 4, npart, opt, QUANT_LEVELS, gid=device_id)
+
+    def symbols(self, x):
+        """quantiser indices in wavefront layout (npart, valid_dim/4, 2h, 2w)"""
+        with torch.no_grad():
+            _, code_i = self.quant(self.encoder(self.slice(x)))
+            return self.dtw(self.ext(code_i))
+
+    def forward(self, x, code_name):
+        with torch.no_grad():
+            hcode_i = self.symbols(x)
+            self.ent.start(code_name)
+            self.ent(hcode_i)
+
+
+class PseudoDecoder(nn.Module):
+    """code file -> ERP image (reference: pseudo_codec.py:188-213).  height/width
+    default to the reference's only size."""
+
+    def __init__(self, valid_dim, device_id):
+        super(PseudoDecoder, self).__init__()
+        self.npart, opt, self.channels, self.code_channels = NPART, True, CHANNELS, CHANNELS
+        dev = backend.device_of(device_id)
+        self.valid_dim = valid_dim
+        self.uslice = SphereUslice(self.npart, pad=0, opt=opt, device=device_id)
+        self.ctx = PseudoContextV2(self.npart, opt, device=device_id)
+        self.decoder = DecoderV2(self.channels, self.code_channels, self.npart, self.ctx, device_id).to(dev)
+        self.clip = ClipData()
+        self.quant = PseudoDQUANT(self.code_channels, QUANT_LEVELS, self.npart, self.ctx, device_id=device_id)
+        self.wtd = Dtow(2, False, device_id)
+        self.ent = EntDecoder(self.valid_dim // 4, self.npart, opt, QUANT_LEVELS, gid=device_id)
+
+    def reconstruct(self, hcode_i):
+        """symbols in wavefront layout -> image"""
+        with torch.no_grad():
+            code_ext = self.quant(self.wtd(hcode_i))
+            code_f = torch.zeros((code_ext.shape[0], self.code_channels) + tuple(code_ext.shape[2:])).type_as(code_ext)
+            code_f[:, :self.valid_dim] = code_ext
+            return self.clip(self.uslice(self.decoder(code_f.contiguous())))
+
+    def forward(self, code_name, height=512, width=1024):
+        with torch.no_grad():
+            h, w = latent_shape(height, width, self.npart)
+            self.ent.start(code_name)
+            return self.reconstruct(self.ent(2 * h, 2 * w))
+
+
+# -- image / checkpoint I/O ---------------------------------------------------
+def read_image(path):
+    """uint8 HxWx3 in BGR order (what cv2.imread returns in the reference)"""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1].copy()
+
+
+def write_image(path, img_bgr):
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(img_bgr[:, :, ::-1])).save(path)
+
+
+def img2tensor(img, device):
+    ts = torch.from_numpy(img.transpose(2, 0, 1).astype(np.float32)) / 255.
+    return torch.unsqueeze(ts, 0).to(device).contiguous()
+
+
+def tensor2img(data):
+    return (data[0] * 255.).to('cpu').detach().numpy().transpose(1, 2, 0).astype(np.uint8)
+
+
+def check_img(img, height=512, width=1024):
+    """bicubic resize to the coding size when the input differs (reference: pseudo_codec.py:229-234)"""
+    if img.shape[0] == height and img.shape[1] == width:
+        return img
+    from PIL import Image
+    return np.asarray(Image.fromarray(img).resize((width, height), Image.BICUBIC))
+
+
+def load_models(model, p1, p2, device):
+    merged = OrderedDict(**torch.load(p1, map_location=device), **torch.load(p2, map_location=device))
+    model.load_state_dict(merged)
+
+
+def _pick(model_idx, mse):
+    prex = model_mse_list[model_idx] if mse else model_ssim_list[model_idx]
+    vd = mse_channel_list[model_idx] if mse else ssim_channel_list[model_idx]
+    return prex, vd, (mse_model_dir if mse else ssim_model_dir)
+
+
+def bitrate(path, height=512, width=1024):
+    return os.path.getsize(path) * 8 / float(width) / float(height)
+
+
+def encoding(img_list, out_list, model_idx=0, mse=True, device_id=0, height=512, width=1024):
+    prex, vd, model_dir = _pick(model_idx, mse)
+    dev = backend.device_of(device_id)
+    t1 = PseudoEncoder(vd, device_id=device_id).to(dev)
+    load_models(t1, '{}/{}_encoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
+    for fn, fo in zip(img_list, out_list):
+        data = img2tensor(check_img(read_image(fn), height, width), dev)
+        t1(data, fo)
+        print('Encoding {}, bitrate: {:.3f}bpp'.format(fn, bitrate(fo, height, width)))
+
+
+def decoding(code_list, decoded_img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024):
+    prex, vd, model_dir = _pick(model_idx, mse)
+    dev = backend.device_of(device_id)
+    t1 = PseudoDecoder(vd, device_id=device_id).to(dev)
+    load_models(t1, '{}/{}_decoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
+    for fc, fo in zip(code_list, decoded_img_list):
+        write_image(fo, tensor2img(t1(fc, height, width)))
+        print('Decoding {}, output to {}'.format(fc, fo))
+
+
+class ViewportMetrics(object):
+    """viewport PSNR / SSIM of the paper: 14 rectilinear views, 171x256, FoV pi/2
+    (reference: pseudo_codec.py:270-282)"""
+
+    def __init__(self, device_id=0):
+        dev = backend.device_of(device_id)
+        self.pr1 = MultiProject(171, int(171 * 1.5), 0.5, False, device_id).to(dev)
+        self.pr2 = MultiProject(171, int(171 * 1.5), 0.5, False, device_id).to(dev)
+        self.sim_func = SSIM(11, 3).to(dev)
+
+    def __call__(self, original, decoded):
+        x, y = self.pr1(original), self.pr2(decoded)
+        mse_loss = torch.mean((x - y) ** 2).item()
+        return psnr_f(mse_loss), self.sim_func(x, y).item()
+
+
+def decoding_and_test(code_list, img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024):
+    prex, vd, model_dir = _pick(model_idx, mse)
+    dev = backend.device_of(device_id)
+    t1 = PseudoDecoder(vd, device_id=device_id).to(dev)
+    load_models(t1, '{}/{}_decoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
+    metrics = ViewportMetrics(device_id)
+    rows = []
+    for fc, fn in zip(code_list, img_list):
+        rdata = t1(fc, height, width)
+        data = img2tensor(check_img(read_image(fn), height, width), dev)
+        pr, vssim = metrics(data, rdata)
+        rt = bitrate(fc, height, width)
+        rows.append((rt, pr, vssim))
+        print('Decoding {}, compare it to {} \n Bitrate:{:.3f}bpp, PSNR:{:.2f}dB, SSIM:{:.4f}'.format(fc, fn, rt, pr, vssim))
+    print('-' * 53 + '\nAverage Performance\n' + '-' * 53)
+    rt, pr, vssim = np.average(np.array(rows), axis=0)
+    print('Bitrate:{:.3f}bpp, PSNR:{:.2f}dB, SSIM:{:.4f}'.format(rt, pr, vssim))
+
+
+def read_list(fname):
+    with open(fname) as f:
+        return [line.rstrip('\n') for line in f.readlines()]
+
+
+def check_models():
+    assert os.path.exists('{}/{}_encoder.pt'.format(mse_model_dir, model_mse_list[0])), \
+        'Please make sure the pretrained models for VMSE exists in the mse_model_dir'
+    assert os.path.exists('{}/{}_encoder.pt'.format(ssim_model_dir, model_ssim_list[0])), \
+        'Please make sure the pretrained models for VSSIM exists in the ssim_model_dir'
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='Pseudo Convolution for 360 Image Compression')
+    parser.add_argument('--img-list', nargs='*', help='The image list contains the input images for encoding and testing')
+    parser.add_argument('--code-list', nargs='*', help='The code file list for codes')
+    parser.add_argument('--out-list', nargs='*', help='The out list for saving decoded images.')
+    parser.add_argument('--img-file', help='The file contains the input images for encoding and testing')
+    parser.add_argument('--code-file', help='The file contains the list for codes')
+    parser.add_argument('--out-file', help='The file  contains the names of decoded images.')
+    parser.add_argument('--model-idx', type=int, default=0, help='Model index (0-9) for VMSE, (0-8) for VSSIM')
+    parser.add_argument('--enc', action='store_true', default=False, help='Encoding flag, set for encoding phase.')
+    parser.add_argument('--dec', action='store_true', default=False, help='Decoding flag, set for decoding phase.')
+    parser.add_argument('--test', action='store_true', default=False, help='Testing flag, set for decoding and evalating the performance.')
+    parser.add_argument('--ssim', action='store_true', default=False,
+                        help='Default with models optimized for VMSE, set this flag for choosing the models optimized for VSSIM')
+    parser.add_argument('--gpu-id', type=int, default=0, help='The graphic card id for encoding and decoding.')
+    parser.add_argument('--height', type=int, default=512, help='ERP height of the coded image (multiple of 256)')
+    parser.add_argument('--width', type=int, default=1024, help='ERP width of the coded image (multiple of 16)')
+    args = parser.parse_args(argv)
+    check_models()
+    midx = args.model_idx
+    if args.ssim:
+        assert 0 <= midx < 9, '(0-8) for VSSIM'
+    else:
+        assert 0 <= midx < 10, '(0-9) for VMSE'
+    assert args.enc or args.dec or args.test, \
+        'Should set one flag, (--enc) for encoding, (--dec) for decoding, (--test) for testing.'
+    pick = lambda lst, fil: lst if lst is not None else (read_list(fil) if fil is not None else None)
+    img_list, code_list, out_list = pick(args.img_list, args.img_file), pick(args.code_list, args.code_file), \
+        pick(args.out_list, args.out_file)
+    size = dict(height=args.height, width=args.width)
+    if args.enc:
+        assert img_list is not None, 'No input images for encoding'
+        assert code_list is not None, 'No code files for saving the codes'
+        assert len(img_list) == len(code_list), 'The number of images and codes should be the same'
+        encoding(img_list, code_list, midx, not args.ssim, args.gpu_id, **size)
+    else:
+        assert code_list is not None, 'No code files for decoding'
+        if args.dec:
+            assert out_list is not None, 'No out files for saving the decoded images'
+            assert len(code_list) == len(out_list), 'The number of codes and reconstructed images should be the same'
+            decoding(code_list, out_list, midx, not args.ssim, args.gpu_id, **size)
+        else:
+            assert img_list is not None, 'No source images for evaluation.'
+            assert len(code_list) == len(img_list), 'The number of codes and corresponding source images should be the same'
+            decoding_and_test(code_list, img_list, midx, not args.ssim, args.gpu_id, **size)
+
+
+if __name__ == '__main__':
+    main()
