@@ -454,7 +454,7 @@ static void o_mrod(const float *x, const float *y, const float *z, float *data, 
   for (int i = 0; i < n; i++) {
     int base = i * 9;
     for (int k = 0; k < 9; k++) data[base + k] = 0;
-    float norm = sqrt(x[i] * x[i] + y[i] * y[i] + z[i] * z[i]);
+    float norm = sqrtf(x[i] * x[i] + y[i] * y[i] + z[i] * z[i]);
     if (norm == 0) {
       data[base] = 1.;
       data[base + 4] = 1.;
@@ -462,7 +462,7 @@ static void o_mrod(const float *x, const float *y, const float *z, float *data, 
       continue;
     }
     float tx = x[i] / norm, ty = y[i] / norm, tz = z[i] / norm;
-    float c = cos(norm), s = sin(norm);
+    float c = cosf(norm), s = sinf(norm);
     data[base + 0] = c + (1 - c) * tx * tx;
     data[base + 1] = (1 - c) * tx * ty - s * tz;
     data[base + 2] = (1 - c) * tx * tz + s * ty;
@@ -475,7 +475,9 @@ static void o_mrod(const float *x, const float *y, const float *z, float *data, 
   }
 }
 
-/* builds tf (nv*h_out*w_out*2) for an ERP of height x width */
+/* builds tf (nv*h_out*w_out*2) for an ERP of height x width.  The reference is
+ * C++/CUDA: sqrt/sin/cos/asin/atan of a float argument resolve to the float
+ * overloads there, hence the explicit ...f calls in this C restatement. */
 void orc_projects_table(const float *theta_in, const float *phi_in, int nv, float fov_in, int h_out,
                         int w_out, int height, int width, float *tf) {
   float pi_ = acos(-1.0);
@@ -494,15 +496,15 @@ void orc_projects_table(const float *theta_in, const float *phi_in, int nv, floa
   float pi_2 = pi_ / 2;
   float wangle = pi_2 - wfov;
   float hangle = pi_2 - hfov;
-  float w_stride = 2 * sin(wfov) / sin(wangle) / (w_out - 1);
-  float h_stride = 2 * sin(hfov) / sin(hangle) / (h_out - 1);
+  float w_stride = 2 * sinf(wfov) / sinf(wangle) / (w_out - 1);
+  float h_stride = 2 * sinf(hfov) / sinf(hangle) / (h_out - 1);
   for (int i = 0; i < nv * inner; i++) { /* projects_init_xyz_kernel */
     int w = i % w_out;
     int h = (i / w_out) % h_out;
     float x = 1.;
     float y = (w - c_x) * w_stride;
     float z = (h - c_y) * h_stride;
-    float r = sqrt(x * x + y * y + z * z);
+    float r = sqrtf(x * x + y * y + z * z);
     xyz[i * 3] = x / r;
     xyz[i * 3 + 1] = y / r;
     xyz[i * 3 + 2] = -z / r;
@@ -540,10 +542,10 @@ void orc_projects_table(const float *theta_in, const float *phi_in, int nv, floa
   float hx = (width - 1) / 2.0;
   float hy = (height - 1) / 2.0;
   for (int i = 0; i < nv * inner; i++) { /* projects_cal_xyz_kernel */
-    float lat = asin(xyz[i * 3 + 2]);
+    float lat = asinf(xyz[i * 3 + 2]);
     float tx = xyz[i * 3];
     float ty = xyz[i * 3 + 1];
-    float th = atan(ty / tx);
+    float th = atanf(ty / tx);
     if (tx <= 0) {
       if (ty > 0)
         th = th + pi_;

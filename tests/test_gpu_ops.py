@@ -1,0 +1,298 @@
+"""GPU parity of every hot-path op: HIP kernel (through the C ABI) vs the CPU
+oracle on the same seeded inputs.  Integer / index work and every gather/lerp
+kernel must match bit for bit (both sides evaluate the same IEEE operations in
+the same order, contraction off); the dense convolution matches the fmaf-chain
+oracle bit for bit and torch's CPU conv within 1e-4 (north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pconv_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+W16 = [15., 31., 54., 63., 63., 64., 64., 64., 64., 64., 64., 63., 63., 54., 31., 15.]
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _detmath():
+    O.set_detmath(True)
+    yield
+
+
+def P():
+    from pseudocylindrical_convolution_amd import PCONV
+    return PCONV
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * scale).contiguous()
+
+
+def same(a_gpu, b_cpu):
+    a = a_gpu.detach().cpu()
+    assert a.shape == b_cpu.shape
+    assert torch.equal(a, b_cpu), "max abs diff %g" % (a - b_cpu).abs().max().item()
+
+
+@pytest.mark.parametrize("shape,pad", [((1, 3, 512, 1024), 0), ((2, 2, 256, 512), 0), ((1, 1, 256, 320), 1)])
+def test_sphere_slice(shape, pad):
+    x = rnd(*shape, seed=1)
+    g = P().SphereSliceOp(16, 0, pad, W16, 0, False).forward(x.to(DEV))[0]
+    c = O.SphereSliceOp(16, 0, pad, W16).forward(x)[0]
+    if pad:
+        p = pad
+        same(g[:, :, p:-p, p:-p], c[:, :, p:-p, p:-p].contiguous())
+    else:
+        same(g, c)
+    # columns at or beyond the tile width are exactly zero
+    widths = O.widths_v3(W16, 16, shape[2], shape[3])
+    gi = g[:, :, pad:g.shape[2] - pad, pad:g.shape[3] - pad].cpu()
+    for t in range(16):
+        assert gi[t::16, :, :, int(widths[t]):].abs().max().item() == 0 if widths[t] < shape[3] else True
+
+
+@pytest.mark.parametrize("shape,pad", [((16, 3, 32, 1024), 0), ((32, 2, 16, 512), 0), ((16, 2, 18, 516), 2)])
+def test_sphere_uslice(shape, pad):
+    x = rnd(*shape, seed=2)
+    g = P().SphereUsliceOp(16, 0, pad, W16, 0, False).forward(x.to(DEV))[0]
+    c = O.SphereUsliceOp(16, 0, pad, W16).forward(x)[0]
+    same(g, c)
+
+
+@pytest.mark.parametrize("shape,pad", [((16, 4, 16, 512), 1), ((16, 3, 8, 256), 2), ((32, 2, 2, 64), 2),
+                                       ((16, 2, 32, 1024), 1)])
+def test_pseudo_pad(shape, pad):
+    x = rnd(*shape, seed=3)
+    gctx = P().PseudoContextOp(16, 20, W16, 0, False)
+    octx = O.PseudoContextOp(16, 20, W16)
+    # zero the dead columns first, as the network does
+    xg = P().PseudoFillOp(0, 16, 0, 0, gctx.addr(), 0, 0, False).forward(x.clone().to(DEV))[0]
+    xc = O.PseudoFillOp(0, 16, 0, 0, octx.addr(), 0).forward(x.clone())[0]
+    same(xg, xc)
+    g = P().PseudoPadOp(pad, 16, gctx.addr(), 0, False).forward(xg)[0]
+    c = O.PseudoPadOp(pad, 16, octx.addr()).forward(xc)[0]
+    same(g, c)
+    # inside each tile's valid width the interior of the padded tensor is the input
+    widths = O.widths_v3(W16, 16, 16 * shape[2], shape[3])
+    inner = g[:, :, pad:-pad, pad:-pad].cpu()
+    for t in range(16):
+        v = int(widths[t])
+        assert torch.equal(inner[t::16, :, :, :v], xc[t::16, :, :, :v])
+
+
+def test_pseudo_pad_unmasked_input():
+    # also exact when the dead columns hold garbage (pad must not read them)
+    x = rnd(16, 2, 4, 128, seed=4)
+    gctx = P().PseudoContextOp(16, 20, W16, 0, False)
+    octx = O.PseudoContextOp(16, 20, W16)
+    same(P().PseudoPadOp(2, 16, gctx.addr(), 0, False).forward(x.to(DEV))[0],
+         O.PseudoPadOp(2, 16, octx.addr()).forward(x)[0])
+
+
+@pytest.mark.parametrize("pad,trim,fvalue", [(0, 0, 0), (2, 0, 0), (2, 1, 3), (1, 1, -1)])
+def test_pseudo_fill(pad, trim, fvalue):
+    x = rnd(32, 3, 10, 132, seed=5)
+    gctx = P().PseudoContextOp(16, 20, W16, 0, False)
+    octx = O.PseudoContextOp(16, 20, W16)
+    op = P().PseudoFillOp(pad, 16, fvalue, trim, gctx.addr(), 0, 0, False)
+    xg = x.clone().to(DEV)
+    g = op.forward(xg)[0]
+    assert g.data_ptr() == xg.data_ptr()  # in place, returns its input
+    c = O.PseudoFillOp(pad, 16, fvalue, trim, octx.addr(), 0).forward(x.clone())[0]
+    same(g, c)
+    same(op.forward(g)[0], c)  # idempotent
+
+
+@pytest.mark.parametrize("shape,stride", [((16, 56, 2, 64), 2), ((3, 36, 5, 7), 3), ((16, 768, 4, 32), 2),
+                                          ((2, 12, 6, 10), 2)])
+def test_dtow_roundtrip(shape, stride):
+    x = rnd(*shape, seed=6)
+    d = P().DtowOp(stride, True, 0, False)
+    w = P().DtowOp(stride, False, 0, False)
+    g = d.forward(x.to(DEV))[0]
+    same(g, O.DtowOp(stride, True).forward(x)[0])
+    back = w.forward(g)[0]
+    same(back, x)
+    same(back, O.DtowOp(stride, False).forward(g.cpu())[0])
+
+
+def test_quant_dquant():
+    x = rnd(16, 192, 2, 64, seed=7)
+    weight = torch.zeros(192, 8)
+    weight[:, 0] = 1. / 9
+    weight[:, 1:] = float(np.log(1. / 9))
+    weight += rnd(192, 8, seed=8) * 0.05
+    count = torch.zeros(192, 8)
+    gctx = P().PseudoContextOp(16, 20, W16, 0, False)
+    octx = O.PseudoContextOp(16, 20, W16)
+    gv, gi = P().PseudoQuantOp(192, 8, 16, 0.9, 100, 2, 0.1, gctx.addr(), 0, False).forward(
+        x.to(DEV), weight.to(DEV), count.to(DEV), False)
+    cv, ci = O.PseudoQuantOp(192, 8, 16, 0.9, 100, 2, 0.1, octx.addr()).forward(x, weight, count, False)
+    same(gi, ci)
+    same(gv, cv)
+    assert ci.max() <= 7 and ci.min() >= 0
+    sub = ci[:, :56].contiguous()
+    gd = P().PseudoDQuantOp(16, 192, 8, gctx.addr(), 0, False).forward(sub.to(DEV), weight.to(DEV))[0]
+    cd = O.PseudoDQuantOp(16, 192, 8, octx.addr()).forward(sub, weight)[0]
+    same(gd, cd)
+
+
+def test_projects():
+    x = rnd(1, 3, 512, 1024, seed=9)
+    th = [-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0]
+    ph = [0, 0, 0, 0, 0.25, 0.25, 0.25, 0.25, -0.25, -0.25, -0.25, -0.25, 0.5, -0.5]
+    for near in (False, True):
+        g = P().ProjectsOp(171, 256, th, ph, 0.5, near, 0, False).forward(x.to(DEV))[0]
+        c = O.ProjectsOp(171, 256, th, ph, 0.5, near).forward(x)[0]
+        assert g.shape == (14, 3, 171, 256)
+        same(g, c)
+
+
+def test_context_reshape_mask_gmm_loss():
+    x = rnd(2, 42, 5, 7, seed=10)
+    same(P().ContextReshapeOp(14, 0, False).forward(x.to(DEV))[0], O.ContextReshapeOp(14).forward(x)[0])
+    for constrain in (1, 2, 5, 6):
+        w = rnd(42, 42, 5, 5, seed=11) + 0.5
+        wg = w.clone().to(DEV)
+        P().MaskConstrainOp(constrain, 14, 0, False).forward(wg)
+        wc = w.clone()
+        O.MaskConstrainOp(constrain, 14).forward(wc)
+        same(wg, wc)
+    m = 257
+    wt = torch.softmax(rnd(m, 3, seed=12), 1).contiguous()
+    dl = rnd(m, 3, seed=13) * 3 + 0.05
+    mu = rnd(m, 3, seed=14) * 8 - 3.5
+    lb = torch.randint(0, 8, (m, 1), generator=torch.Generator().manual_seed(15)).float() - 3.5
+    g = P().EntropyGmmOp(3, 0, 0, False).forward(wt.to(DEV), dl.to(DEV), mu.to(DEV), lb.to(DEV))[0]
+    c = O.EntropyGmmOp(3, 0).forward(wt, dl, mu, lb)[0]
+    assert (g.cpu() - c).abs().max().item() < 1e-5
+
+
+def test_gmm_table_matches_oracle_and_is_a_cdf():
+    n = 4000
+    g = torch.Generator().manual_seed(16)
+    raw = torch.randn(3, 3, 40, 100, generator=g) * 2   # sections: weights | deltas | means
+    raw[1] = raw[1].abs() * 1.5 - 0.1                     # some negative deltas -> beta
+    raw[2] = raw[2] * 2
+    tnum = torch.tensor([n], dtype=torch.int32)
+    dg = raw.clone().to(DEV)
+    tg = P().EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, 0, False).forward_batch(dg, tnum)[0]
+    dc = raw.clone()
+    tc = O.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6).forward_batch(dc, tnum)[0]
+    same(tg[:n], tc[:n].contiguous())
+    same(dg.view(-1)[:n * 3], dc.view(-1)[:n * 3].contiguous())  # softmax written in place
+    rows = tg[:n].cpu()
+    assert (rows[:, 0] == 0).all() and (rows[:, 8] == 65536).all()
+    assert (rows[:, 1:] - rows[:, :-1] >= 1).all()
+    # libm erf instead of the published polynomial: at most one count apart, rarely
+    O.set_detmath(False)
+    tl = O.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6).forward_batch(raw.clone(), tnum)[0][:n]
+    diff = (rows - tl).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 0.02
+
+
+def _wavefront_net(mod, nimg, h, w, ngroup, seed, steps=None):
+    """drive DInput2 -> [pad -> conv(+act)] x2 -> add -> extract for all steps with
+    backend `mod`; returns everything observable"""
+    dev = DEV if mod is not O else "cpu"
+    ctx = mod.EntropyContextOp(16, 18, W16, 0, False)
+    ctx.start_context(w)
+    addr = ctx.addr()
+    g = torch.Generator().manual_seed(seed)
+    w1 = (torch.randn(3, ngroup * 3, ngroup * 1, 5, 5, generator=g) * 0.2).to(dev)
+    b1 = (torch.randn(3, ngroup * 3, generator=g) * 0.1).to(dev)
+    a1 = (torch.rand(3, ngroup * 3, generator=g)).to(dev)
+    w2 = (torch.randn(3, ngroup * 3, ngroup * 3, 5, 5, generator=g) * 0.1).to(dev)
+    b2 = (torch.randn(3, ngroup * 3, generator=g) * 0.1).to(dev)
+    a2 = (torch.rand(3, ngroup * 3, generator=g)).to(dev)
+    w3 = (torch.randn(3, ngroup * 3, ngroup * 3, 5, 5, generator=g) * 0.1).to(dev)
+    b3 = (torch.randn(3, ngroup * 3, generator=g) * 0.1).to(dev)
+    data = torch.randint(0, 8, (nimg * 16, ngroup, h, w), generator=g).float().to(dev)
+    fill = mod.PseudoFillOp(0, 16, 0, 0, addr, 2, 0, False)
+    data = fill.forward(data)[0]
+    ipt = mod.DInput2Op(ngroup, 16, 2, -3.5, 3, addr, 0, False)
+    pad1 = mod.EntropyCtxPadRun2Op(2, 16, ngroup, True, addr, 0, False)
+    conv1 = mod.EntropyConv2Op(16, ngroup, ngroup, ngroup * 3, 5, 5, 2, 2, addr, 0, False)
+    pad2 = mod.EntropyCtxPadRun2Op(2, 16, ngroup, False, addr, 0, False)
+    conv2 = mod.EntropyConv2Op(16, ngroup * 3, ngroup, ngroup * 3, 5, 6, 2, 2, addr, 0, False)
+    add = mod.EntropyAddOp(16, ngroup * 3, ngroup, 2, addr, 0, False)
+    pad3 = mod.EntropyCtxPadRun2Op(2, 16, ngroup, False, addr, 0, False)
+    conv3 = mod.EntropyConv2Op(16, ngroup * 3, ngroup, ngroup * 3, 5, 6, 2, 0, addr, 0, False)
+    ext = mod.DExtract2Op(16, ngroup, True, addr, 0, False)
+    lab = mod.DExtract2Op(16, ngroup, True, addr, 0, False)
+    gmm = mod.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, 0, False)
+    label = torch.zeros((nimg, 1, h * 16, w), device=dev)
+    nsteps = h * 16 + w + ngroup - 2 if steps is None else steps
+    tables, counts = [], []
+    for _ in range(nsteps):
+        b = ipt.forward(label)[0]
+        y1 = conv1.forward_act_batch(pad1.forward(b)[0], w1, b1, a1)[0]
+        y2 = conv2.forward_act_batch(pad2.forward(y1)[0], w2, b2, a2)[0]
+        y2 = add.forward(y2, y1)[0]
+        y3 = conv3.forward_batch(pad3.forward(y2)[0], w3, b3)[0]
+        z, le = ext.forward_batch(y3)
+        vec = gmm.forward_batch(z, le)[0]
+        n = int(le[0])
+        label, _ = lab.forward(data)
+        tables.append(vec[:n].detach().cpu().clone())
+        counts.append(n)
+    return dict(ctx=b.cpu(), y1=y1.cpu(), y2=y2.cpu(), y3=y3.cpu(), tables=tables, counts=counts, data=data.cpu())
+
+
+@pytest.mark.parametrize("nimg,h,w,ngroup", [(1, 2, 64, 14), (2, 1, 64, 4)])
+def test_entropy_wavefront_ops_bit_exact(nimg, h, w, ngroup):
+    g = _wavefront_net(P(), nimg, h, w, ngroup, seed=21)
+    c = _wavefront_net(O, nimg, h, w, ngroup, seed=21)
+    assert g["counts"] == c["counts"]
+    assert sum(g["counts"]) == int((g["data"].shape[1] * h * nimg) * sum(int(x) for x in O.widths_v3(W16, 16, 16 * h, w)))
+    for k in ("ctx", "y1", "y2", "y3"):
+        assert torch.equal(g[k], c[k]), k
+    for tg, tc in zip(g["tables"], c["tables"]):
+        assert torch.equal(tg, tc)
+    # the scattered context equals the symbols minus 3.5 inside the valid region
+    ctx = g["ctx"][:nimg * 16, :, 2:-2, 2:-2]
+    widths = O.widths_v3(W16, 16, 16 * h, w)
+    for t in range(16):
+        v = int(widths[t])
+        assert torch.equal(ctx[t::16, :, :, :v] + 3.5, g["data"][t::16, :, :, :v])
+
+
+@pytest.mark.parametrize("cfg", [
+    # tn, cin, h, w, cout, k, stride
+    (2, 192, 6, 70, 192, 3, 1), (1, 96, 5, 66, 96, 3, 1), (2, 3, 9, 131, 192, 3, 2), (1, 192, 4, 64, 12, 3, 1),
+    (2, 192, 4, 70, 96, 1, 1), (1, 96, 3, 64, 192, 1, 1), (2, 192, 5, 131, 192, 1, 2), (1, 192, 4, 66, 768, 3, 1),
+    (1, 192, 7, 130, 192, 3, 2), (3, 20, 3, 40, 40, 3, 1),
+])
+def test_tile_conv_bit_exact_vs_fmaf_chain(cfg):
+    tn, cin, h, w, cout, k, stride = cfg
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(tn, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g)
+    sl = torch.rand(cout, generator=g)
+    owner = type("Owner", (), {})()
+    for slope in (None, sl):
+        y = P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), stride,
+                            slope.to(DEV) if slope is not None else None)
+        ref = O.conv2d_chain(x, wt, b, stride, slope)
+        same(y, ref)
+        t = O.tile_conv2d(None, x, wt, b, stride, slope)
+        assert (y.cpu() - t).abs().max().item() < 1e-4
+
+
+def test_tile_conv_dead_column_skip():
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(16, 8, 4, 258, generator=g)
+    wt = torch.randn(32, 8, 3, 3, generator=g) * 0.1
+    b = torch.randn(32, generator=g)
+    limit = torch.tensor([70, 128, 129, 256, 0, 64, 1, 300] * 2, dtype=torch.int32)
+    owner = type("Owner", (), {})()
+    y = P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 1, None, limit.to(DEV), 16).cpu()
+    ref = O.conv2d_chain(x, wt, b, 1, None)
+    for t in range(16):
+        first_dead = ((int(limit[t]) + 63) // 64) * 64 if limit[t] > 0 else 0
+        assert torch.equal(y[t, :, :, :first_dead], ref[t, :, :, :first_dead])
+        assert y[t, :, :, first_dead:].abs().max().item() == 0 if first_dead < 256 else True
