@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ERP MPix/s, encode + decode, 4096x2048 frames, model-idx 3
+(--ssim => valid_dim 56), synthetic frames and seeded random weights.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = every rank encodes and decodes its own shard of frames
+(--frames-per-gpu, independent frames, no data-path collective: weak scaling).
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (fp32-MFMA tile conv, 3x3 stride-1, 192-cout
+                tile) timed with events on its launch stream during the timed steps
+  cpu_baseline  the CPU oracle port of the same codec on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+VALID_FRACTION = 836.0 / 1024.0      # valid columns / all columns
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md, dense fp32 matrix peak
+MODEL_VALID_DIM = 56                 # model-idx 3 of the --ssim list (pseudo_codec.py:18-19)
+
+
+def make_codec(device_id, vd=MODEL_VALID_DIM):
+    from pseudocylindrical_convolution_amd import pseudo_codec as PC
+    torch.manual_seed(1234)
+    enc, dec = PC.PseudoEncoder(vd, device_id), PC.PseudoDecoder(vd, device_id)
+    g = torch.Generator().manual_seed(7)
+    # the reference's default torch.rand init makes degenerate CDFs
+    sd = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in enc.ent.state_dict().items()}
+    enc.ent.load_state_dict(sd)
+    dec.ent.load_state_dict(sd)
+    dec.quant.weight.data.copy_(enc.quant.weight.data)
+    return enc, dec
+
+
+def synthetic_frame(h, w, seed, device):
+    """smooth low-frequency ERP frame plus a little noise, in [0, 1]"""
+    g = torch.Generator().manual_seed(seed)
+    yy = torch.linspace(0, 1, h).view(1, 1, h, 1)
+    xx = torch.linspace(0, 1, w).view(1, 1, 1, w)
+    ph = torch.rand(3, 4, generator=g) * 6.28318
+    chans = []
+    for c in range(3):
+        v = 0.5 + 0.2 * torch.sin(6.28318 * (2 + c) * xx + ph[c, 0]) * torch.cos(3.14159 * (1 + c) * yy + ph[c, 1]) \
+            + 0.15 * torch.sin(6.28318 * 7 * xx + 12.566 * yy + ph[c, 2])
+        chans.append(v)
+    img = torch.cat(chans, 1) + 0.04 * torch.rand(1, 3, h, w, generator=g)
+    return img.clamp_(0, 1).to(device).contiguous()
+
+
+class ConvProbe(object):
+    """collects (kernel key, flops, start event, end event) of tile-conv launches"""
+
+    def __init__(self):
+        self.records = []
+
+    def summarise(self):
+        torch.cuda.synchronize()
+        per = {}
+        for key, flops, e0, e1 in self.records:
+            t = e0.elapsed_time(e1) * 1e-3
+            d = per.setdefault(key, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += t
+            d[2] += 1
+        return per
+
+
+def cpu_baseline(sample_h, sample_w):
+    """CPU oracle port of the same encode+decode on one bounded frame"""
+    from pseudocylindrical_convolution_amd.PCONV_operator import backend
+    from oracle import pconv_cpu, coder_cpu
+    backend.use(pconv_cpu, coder_cpu)
+    pconv_cpu.set_detmath(True)
+    try:
+        enc, dec = make_codec(0)
+        x = synthetic_frame(sample_h, sample_w, 100, "cpu")
+        path = os.path.join(tempfile.mkdtemp(), "cpu.bin")
+        t0 = time.perf_counter()
+        enc(x, path)
+        dec(path, sample_h, sample_w)
+        dt = time.perf_counter() - t0
+    finally:
+        backend.reset()
+    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "1 frame %dx%d enc+dec, %.1f s (oracle C kernels + torch CPU conv)" % (sample_w, sample_h, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--frames-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="512x1024", help="HxW of the CPU baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+
+    from pseudocylindrical_convolution_amd import PCONV
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = make_codec(local)
+    codec = CodecEngine(MODEL_VALID_DIM, local, enc, dec)
+    H, W, F = args.height, args.width, args.frames_per_gpu
+    frames = torch.cat([synthetic_frame(H, W, 100 + rank * F + i, dev) for i in range(F)], 0)
+    state = {"bits": 0}
+
+    def step():
+        # frames of the shard are coded in lock-step; streams stay in host memory
+        streams = codec.encode(frames)
+        rec = codec.decode(streams, H, W)
+        state["bits"] = sum(len(s) for s in streams) * 8
+        return rec
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    probe = ConvProbe()
+    PCONV.conv_probe = probe
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    PCONV.conv_probe = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    per_kernel = probe.summarise()
+    total_pix = float(world * F * args.steps) * H * W
+    bits = state["bits"]
+    out = None
+    if rank == 0:
+        dom_key = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None
+        roof = None
+        if dom_key is not None:
+            fl, tt, n = per_kernel[dom_key]
+            ach = fl / tt / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel[%s]" % dom_key, "achieved": round(ach, 2),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "launches": n, "avg_launch_ms": round(tt / n * 1e3, 4), "traffic": None}
+        conv_s = sum(v[1] for v in per_kernel.values()) / max(args.steps, 1)
+        out = {
+            "metric": "ERP MPix/s enc+dec, 4096x2048 model-idx 3", "value": round(total_pix / elapsed / 1e6, 4),
+            "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ERP %dx%d encode+decode, model-idx 3 --ssim (valid_dim 56), %d frame(s)/GPU/step"
+                                   % (W, H, F), "frames_per_gpu": F, "bpp": round(bits / float(F * H * W), 4),
+                       "parallelism": "frames sharded, no data-path collective",
+                       "tile_conv_s_per_step": round(conv_s, 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sh, sw = (int(v) for v in args.cpu_sample.split("x"))
+            out["cpu_baseline"] = cpu_baseline(sh, sw)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

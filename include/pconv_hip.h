@@ -23,6 +23,7 @@
 #ifndef PCONV_HIP_H
 #define PCONV_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -236,6 +237,38 @@ int pconv_dextract2_batch(const float *x, float *out, const int32_t *order, int 
 int pconv_gmm_table(float *weight, float *delta, const float *mean, float *table, int tn,
                     int ng, int nstep, float bias, float total, float beta, int batch_arith,
                     void *stream);
+
+/* decoded symbols out of the padded context tensor (tn, c, h+2p, w+2p):
+ * out (tn, c, h, w) = interior + bias inside each tile's valid width, 0 elsewhere
+ * (pseudo_codec.py:159-160) */
+int pconv_ctx_to_symbols(const float *ctx, float *out, const int32_t *widths, int tn, int c, int h,
+                         int w, int pad, int npart, float bias, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Native entropy engine: the EntEncoder / EntDecoder loops
+ * (pseudo_codec.py:97-114,145-160) as one C++ host loop over the step kernels
+ * above, `nimg` frames in lock-step, one arithmetic-coded stream per frame.
+ * The streams are byte-identical to what the per-op path writes.
+ * ---------------------------------------------------------------------- */
+typedef struct pconv_entropy_engine pconv_entropy_engine;
+
+/* h, w: rows per tile and columns of the symbol tensor (after Dtow);
+ * tile_weight[npart] as for pconv_host_tile_widths; bias = (levels-1)/2. */
+pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int nimg,
+                                      const float *tile_weight, float bias, int nlevels, float total,
+                                      float beta);
+void pconv_ee_destroy(pconv_entropy_engine *e);
+/* layer 0..11 = net.0.conv, net.1.conv1.conv, net.1.conv2.conv, ..., net.6.conv;
+ * device pointers: weight (3, 3G, cin, 5, 5), bias (3, 3G), slope (3, 3G) or NULL */
+int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, const float *bias,
+                       const float *slope);
+long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e);
+int pconv_ee_steps(const pconv_entropy_engine *e);
+/* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */
+int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream);
+const uint8_t *pconv_ee_stream(const pconv_entropy_engine *e, int img, size_t *nbytes);
+int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, const size_t *nbytes,
+                    float *symbols_out, void *stream);
 
 #ifdef __cplusplus
 }

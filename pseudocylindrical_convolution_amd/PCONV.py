@@ -851,6 +851,13 @@ def packed_conv_weight(owner, weight, stream):
     return packed
 
 
+# when set to an object with a `records` list, every tile-conv launch is bracketed by
+# events on its own stream: (kernel key, algorithmic flops, start, end).  Used by
+# bench.py for the live roofline figure; None in normal operation.
+conv_probe = None
+_VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack
+
+
 def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0):
     """y = conv2d(x, weight, bias, stride) (+ PReLU(slope)), no padding, on the
     fp32 matrix cores.  x (tn, cin, h, w) -> (tn, cout, ho, wo)."""
@@ -863,7 +870,16 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     packed = packed_conv_weight(owner, weight, stream)
     ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
     out = torch.empty((tn, cout, ho, wo), dtype=torch.float32, device=x.device)
+    probe = conv_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(x.device))
     call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
          tn, cin, h, w, cout, k, int(stride), 1 if slope is not None else 0,
          _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart), stream)
+    if probe is not None:
+        e1.record(torch.cuda.current_stream(x.device))
+        tile = "192" if cout > 96 else ("96" if cout > 32 else "32")
+        flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
+        probe.records.append(("k%d s%d cout-tile %s" % (k, stride, tile), flops, e0, e1))
     return out

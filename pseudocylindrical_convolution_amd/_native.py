@@ -51,6 +51,12 @@ _HIP_SIGNATURES = {
     "pconv_dextract2": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "pconv_dextract2_batch": [P, P, P, I, I, I, I, I, I, I, I, I, I, LL, P],
     "pconv_gmm_table": [P, P, P, P, I, I, I, F, F, F, I, P],
+    "pconv_ctx_to_symbols": [P, P, P, I, I, I, I, I, I, F, P],
+    # native entropy engine
+    "pconv_ee_set_layer": [P, I, P, P, P],
+    "pconv_ee_steps": [P],
+    "pconv_ee_encode": [P, P, P],
+    "pconv_ee_decode": [P, P, P, P, P],
 }
 
 _CODER_SIGNATURES = {
@@ -95,6 +101,14 @@ def hip_lib():
         lib.pconv_last_error.argtypes = []
         lib.pconv_abi_version.restype = c_int
         lib.pconv_device_count.restype = c_int
+        lib.pconv_ee_create.argtypes = [I, I, I, I, I, P, F, I, F, F]
+        lib.pconv_ee_create.restype = c_void_p
+        lib.pconv_ee_destroy.argtypes = [P]
+        lib.pconv_ee_destroy.restype = None
+        lib.pconv_ee_symbols_per_image.argtypes = [P]
+        lib.pconv_ee_symbols_per_image.restype = c_longlong
+        lib.pconv_ee_stream.argtypes = [P, I, POINTER(c_size_t)]
+        lib.pconv_ee_stream.restype = POINTER(c_uint8)
         _hip = lib
     return _hip
 
@@ -112,7 +126,9 @@ def coder_lib():
 
 
 def declared_hip_symbols():
-    return sorted(list(_HIP_SIGNATURES) + ["pconv_last_error", "pconv_abi_version", "pconv_device_count"])
+    return sorted(list(_HIP_SIGNATURES) + ["pconv_last_error", "pconv_abi_version", "pconv_device_count",
+                                           "pconv_ee_create", "pconv_ee_destroy", "pconv_ee_symbols_per_image",
+                                           "pconv_ee_stream"])
 
 
 def declared_coder_symbols():

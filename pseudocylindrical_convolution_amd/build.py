@@ -27,6 +27,7 @@ HIP_SOURCES = [
     "entropy.hip",
     "conv.hip",
     "engine.cpp",
+    "coder.cpp",  # the engine drives the arithmetic coder natively
 ]
 CODER_SOURCES = ["coder.cpp"]
 

@@ -78,6 +78,25 @@ __global__ __launch_bounds__(kBlock) void ctx_pad_run2_kernel(
   }
 }
 
+// decoded symbols out of the context tensor: interior + bias, zero in the dead
+// columns (pseudo_codec.py:159-160: b[:npart,:,2:-2,2:-2] + bias, then PseudoFill)
+__global__ __launch_bounds__(kBlock) void ctx_to_symbols_kernel(const float *__restrict__ ctx,
+                                                                float *__restrict__ out,
+                                                                const int32_t *__restrict__ widths, int c,
+                                                                int h, int w, int pad, int npart, float bias,
+                                                                long long total) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int tw = (int)(i % w);
+    const int th = (int)((i / w) % h);
+    const long long plane = i / w / h;
+    const int tg = (int)((plane / c) % npart);
+    float v = 0.f;
+    if (tw < widths[tg]) v = ctx[(plane * (h + 2 * pad) + th + pad) * (w + 2 * pad) + tw + pad] + bias;
+    out[i] = v;
+  }
+}
+
 // entropy_add_cuda.cu:25-44
 __global__ __launch_bounds__(kBlock) void entropy_add_kernel(
     float *__restrict__ y, const float *__restrict__ x, const int32_t *__restrict__ order, int lo,
@@ -270,6 +289,16 @@ extern "C" int pconv_dinput2(const float *packed, float *ctx, const int32_t *ord
                      as_stream(stream), packed, ctx, order, lo, len, nimg, ngroup, npart, h, w, pad,
                      psum, bias, rep);
   PCONV_LAUNCH_CHECK("dinput2");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_ctx_to_symbols(const float *ctx, float *out, const int32_t *widths, int tn, int c,
+                                    int h, int w, int pad, int npart, float bias, void *stream) {
+  PCONV_REQUIRE(ctx && out && widths && tn > 0 && c > 0, "ctx_to_symbols: bad argument");
+  const long long total = (long long)tn * c * h * w;
+  hipLaunchKernelGGL(ctx_to_symbols_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), ctx,
+                     out, widths, c, h, w, pad, npart, bias, total);
+  PCONV_LAUNCH_CHECK("ctx_to_symbols");
   return PCONV_OK;
 }
 

@@ -1,0 +1,132 @@
+"""Batched codec on the native entropy engine.
+
+`EntropyEngine` binds the C++ wavefront loop of libpconv_hip.so
+(include/pconv_hip.h, pconv_ee_*) to the parameters of an EntEncoder / EntDecoder
+module.  `CodecEngine` runs whole frames: transforms through the operator layer
+(hand-written tile convolution, pad, fill ... kernels), entropy coding through the
+engine, several frames in lock-step.  The streams are byte-identical to the ones
+the per-op PseudoEncoder path writes, so either side can decode the other's files.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import PconvError, call
+from .PCONV_operator import set_weight
+from . import pseudo_codec as PC
+
+
+class EntropyEngine(object):
+    """nimg frames in lock-step through the 12-layer context model
+    (reference loops: pseudo_codec.py:97-114, 145-160)."""
+
+    def __init__(self, ent, h, w, nimg, device):
+        self.lib = _native.hip_lib()
+        self.device = torch.device(device)
+        self.h, self.w, self.nimg = int(h), int(w), int(nimg)
+        self.npart, self.ngroup = ent.npart, ent.ngroup
+        weight = np.asarray(set_weight(self.npart, True), dtype=np.float32)
+        with torch.cuda.device(self.device):
+            self.handle = self.lib.pconv_ee_create(self.npart, self.ngroup, self.h, self.w, self.nimg,
+                                                   weight.ctypes.data, float(ent.bias), 8, 65536.0, 1e-6)
+        if not self.handle:
+            raise PconvError("pconv_ee_create failed: %s" % (self.lib.pconv_last_error() or b"").decode())
+        self.bind(ent)
+
+    def bind(self, ent):
+        """point the engine at the module's parameters (kept alive here)"""
+        convs = [ent.net[0].conv]
+        for b in range(1, 6):
+            convs += [ent.net[b].conv1.conv, ent.net[b].conv2.conv]
+        convs.append(ent.net[6].conv)
+        self._params = []
+        for layer, conv in enumerate(convs):
+            tensors = [conv.weight, conv.bias, conv.relu if conv.act else None]
+            held = []
+            for t in tensors:
+                if t is None:
+                    held.append(None)
+                    continue
+                t = t.detach()
+                if t.device != self.device or not t.is_contiguous() or t.dtype != torch.float32:
+                    t = t.to(self.device, torch.float32).contiguous()
+                held.append(t)
+            self._params.append(held)
+            call("pconv_ee_set_layer", self.handle, layer, held[0].data_ptr(), held[1].data_ptr(),
+                 held[2].data_ptr() if held[2] is not None else None)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.pconv_ee_destroy(h)
+
+    @property
+    def symbols_per_image(self):
+        return int(self.lib.pconv_ee_symbols_per_image(self.handle))
+
+    def encode(self, symbols):
+        """symbols (nimg*npart, ngroup, h, w) float indices, dead columns zero -> [bytes] per frame"""
+        expect = (self.nimg * self.npart, self.ngroup, self.h, self.w)
+        if tuple(symbols.shape) != expect or not symbols.is_cuda or not symbols.is_contiguous():
+            raise PconvError("EntropyEngine.encode: expected contiguous GPU tensor %s, got %s" % (expect, tuple(symbols.shape)))
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            call("pconv_ee_encode", self.handle, symbols.data_ptr(), stream)
+        out = []
+        for i in range(self.nimg):
+            n = ctypes.c_size_t(0)
+            p = self.lib.pconv_ee_stream(self.handle, i, ctypes.byref(n))
+            out.append(ctypes.string_at(p, n.value))
+        return out
+
+    def decode(self, streams):
+        if len(streams) != self.nimg:
+            raise PconvError("EntropyEngine.decode: %d streams for %d frames" % (len(streams), self.nimg))
+        bufs = [ctypes.create_string_buffer(s, len(s)) for s in streams]
+        ptrs = (ctypes.c_void_p * self.nimg)(*[ctypes.cast(b, ctypes.c_void_p) for b in bufs])
+        sizes = (ctypes.c_size_t * self.nimg)(*[len(s) for s in streams])
+        out = torch.empty((self.nimg * self.npart, self.ngroup, self.h, self.w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            call("pconv_ee_decode", self.handle, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p),
+                 out.data_ptr(), stream)
+        return out
+
+
+class CodecEngine(object):
+    """frames in, byte streams out, and back: PseudoEncoder / PseudoDecoder
+    (pseudo_codec.py:162-213) with the entropy loops on the native engine."""
+
+    def __init__(self, valid_dim=56, device_id=0, encoder=None, decoder=None):
+        self.device_id = device_id
+        self.device = torch.device("cuda", device_id)
+        self.enc = encoder if encoder is not None else PC.PseudoEncoder(valid_dim, device_id)
+        self.dec = decoder if decoder is not None else PC.PseudoDecoder(valid_dim, device_id)
+        self._engines = {}
+
+    def _engine(self, which, h, w, nimg):
+        key = (which, h, w, nimg)
+        if key not in self._engines:
+            ent = self.enc.ent if which == "enc" else self.dec.ent
+            self._engines[key] = EntropyEngine(ent, h, w, nimg, self.device)
+        return self._engines[key]
+
+    @torch.no_grad()
+    def symbols(self, frames):
+        """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero"""
+        sym = self.enc.symbols(frames)
+        return self.enc.ent.fill(sym)
+
+    @torch.no_grad()
+    def encode(self, frames):
+        sym = self.symbols(frames)
+        eng = self._engine("enc", sym.shape[2], sym.shape[3], frames.shape[0])
+        return eng.encode(sym.contiguous())
+
+    @torch.no_grad()
+    def decode(self, streams, height, width):
+        h, w = PC.latent_shape(height, width, self.dec.npart)
+        eng = self._engine("dec", 2 * h, 2 * w, len(streams))
+        return self.dec.reconstruct(eng.decode(streams))

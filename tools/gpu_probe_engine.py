@@ -1,0 +1,27 @@
+"""GPU probe: CodecEngine timings (transforms + native entropy engine)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pseudocylindrical_convolution_amd.engine import CodecEngine
+from pseudocylindrical_convolution_amd import pseudo_codec as PC
+torch.manual_seed(1234)
+enc, dec = PC.PseudoEncoder(56, 0), PC.PseudoDecoder(56, 0)
+g = torch.Generator().manual_seed(7)
+sd = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in enc.ent.state_dict().items()}
+enc.ent.load_state_dict(sd); dec.ent.load_state_dict(sd); dec.quant.weight.data.copy_(enc.quant.weight.data)
+eng = CodecEngine(56, 0, enc, dec)
+sizes = [(512, 1024, 1), (2048, 4096, 1)] + ([(2048, 4096, 2), (2048, 4096, 4)] if "--batch" in sys.argv else [])
+for (H, W, N) in sizes:
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        sym = eng.symbols(x); torch.cuda.synchronize(); t1 = time.time()
+        e = eng._engine("enc", sym.shape[2], sym.shape[3], N)
+        streams = e.encode(sym.contiguous()); torch.cuda.synchronize(); t2 = time.time()
+        d = eng._engine("dec", sym.shape[2], sym.shape[3], N)
+        out = d.decode(streams); torch.cuda.synchronize(); t3 = time.time()
+        rec = dec.reconstruct(out); torch.cuda.synchronize(); t4 = time.time()
+        tot = t4 - t0
+        print("%dx%d N=%d rep%d: analysis %.3f ent-enc %.3f ent-dec %.3f synthesis %.3f total %.3f s -> %.2f MPix/s bytes %s ok %s"
+              % (H, W, N, rep, t1 - t0, t2 - t1, t3 - t2, t4 - t3, tot, N * H * W / tot / 1e6,
+                 [len(s) for s in streams], torch.equal(out, sym)), flush=True)
