@@ -92,6 +92,13 @@ int pconv_host_causal_halo(const int32_t *widths, int npart, int channel, int he
                            int width, int pad, int32_t *dst, int32_t *src0, int32_t *src1,
                            float *wgt, int32_t *entry_plane, int32_t *plane_start);
 
+/* The same causal halo as a dense lookup table for kernels that compute halo
+ * taps on the fly instead of reading stored ones: entry ((t*2+side)*pad+r)*width+i
+ * = first source column (-1: only column 0 with weight 1-wgt; -2: no value, reads
+ * as zero) and its weight. */
+int pconv_host_causal_table(const int32_t *widths, int npart, int height, int width, int pad,
+                            int32_t *col, float *wgt);
+
 /* Viewport sampling table of MultiProject: tf[14*h_out*w_out*2] = (x, y) source
  * coordinates in an ERP of (height, width).
  * replaces projects_opt::init/update (projects_cuda.cu:7-165). */
@@ -203,14 +210,24 @@ int pconv_ctx_pad_run2(float *data, const int32_t *dst, const int32_t *src0,
 
 /* EntropyConv2Op.forward{,_act,_batch,_act_batch} body
  * (entropy_conv_cuda_v2.cu:61-459).  x (nimg*npart, cin, h+2pi, w+2pi),
- * weight (nset, cout, cin, k, k), bias (nset, cout), slope NULL = no PReLU,
+ * weight (nset, cout, cin, 5, 5), bias (nset, cout), slope NULL = no PReLU,
  * y (nimg*npart, cout, h+2po, w+2po) persistent.  nimg = images incl. replicas,
- * per_set = nimg / nset. */
+ * per_set = nimg / nset.  The step covers planes [first_plane, first_plane+nplane)
+ * of the schedule (`plane_start` is the device copy of pconv_host_wavefront's
+ * prefix array, max_plane_len the longest of those planes); the output group of
+ * plane p is psum - p.
+ * residual (may be NULL, same shape as y): added after the activation, i.e.
+ * EntropyAddOp folded into the epilogue.
+ * widths / vh_col / vh_wgt (may be NULL): pconv_host_causal_table of the input;
+ * when given, halo taps are computed on the fly from tile interiors and the
+ * stored halo of x is never read (no EntropyCtxPadRun2 needed). */
 int pconv_entropy_conv(const float *x, const float *weight, const float *bias,
-                       const float *slope, float *y, const int32_t *order, int lo, int len,
-                       int nimg, int per_set, int cin, int cout, int ngroup, int k,
-                       int constrain, int npart, int h, int w, int pad_in, int pad_out,
-                       int psum, void *stream);
+                       const float *slope, float *y, const int32_t *order,
+                       const int32_t *plane_start, int first_plane, int nplane, int max_plane_len,
+                       int nimg, int per_set, int cin, int cout, int ngroup, int k, int constrain,
+                       int npart, int h, int w, int pad_in, int pad_out, int psum,
+                       const float *residual, const int32_t *widths, const int32_t *vh_col,
+                       const float *vh_wgt, void *stream);
 
 /* EntropyAddOp.forward body, in place y += x (entropy_add_cuda.cu:25-44) */
 int pconv_entropy_add(float *y, const float *x, const int32_t *order, int lo, int len,
@@ -237,6 +254,19 @@ int pconv_dextract2_batch(const float *x, float *out, const int32_t *order, int 
 int pconv_gmm_table(float *weight, float *delta, const float *mean, float *table, int tn,
                     int ng, int nstep, float bias, float total, float beta, int batch_arith,
                     void *stream);
+
+/* Engine step: DExtract2Batch + EntropyBatchGmmTable (+ the label DExtract2) in
+ * one launch, integer output.  y (3*nimg*npart, 3*ngroup, h, w) = last layer;
+ * table int32 [nimg*len][nstep+1]; symbols (nimg*npart, ngroup, h, w) / labels
+ * int32 [nimg*len] may both be NULL. */
+int pconv_step_tables(const float *y, const float *symbols, int32_t *table, int32_t *labels,
+                      const int32_t *order, int lo, int len, int nimg, int ngroup, int npart, int h,
+                      int w, int psum, int nstep, float bias, float total, float beta, void *stream);
+
+/* encoder side of DInput2: scatter ALL symbols at once, ctx (rep*tn, c, h+2p, w+2p)
+ * interior = symbol + bias inside the valid width (the buffer must be zeroed) */
+int pconv_symbols_to_ctx(const float *symbols, float *ctx, const int32_t *widths, int tn, int c,
+                         int h, int w, int pad, int npart, float bias, int rep, void *stream);
 
 /* decoded symbols out of the padded context tensor (tn, c, h+2p, w+2p):
  * out (tn, c, h, w) = interior + bias inside each tile's valid width, 0 elsewhere

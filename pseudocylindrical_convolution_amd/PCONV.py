@@ -205,7 +205,13 @@ class EntropyContextOp(_TileContext):
             call("pconv_host_wavefront", _np_ptr(wh), self.npart_, height, width, _np_ptr(order),
                  _np_ptr(start))
             self._cache[key] = (self._upload(order, like), start)
+            self._cache[("sched_dev",) + key[1:]] = (self._upload(start, like), int(np.diff(start).max()))
         return self._cache[key]
+
+    def schedule_device(self, height, width, like):
+        """(plane_start on the device, longest plane) of the same schedule"""
+        self.schedule(height, width, like)
+        return self._cache[("sched_dev", int(height), int(width), like.device)]
 
     def causal_halo(self, channel, height, width, pad, like):
         key = ("halo", int(channel), int(height), int(width), int(pad), like.device)
@@ -683,6 +689,7 @@ class EntropyConv2Op(_WavefrontOp):
         if self._reshaped((num, channel, h, w)):
             self.pidx_ = 0
         order, start = self.ctx_.schedule(h, w, x)
+        start_dev, longest = self.ctx_.schedule_device(h, w, x)
         top = self._out(0, (num, self.nout_, h + 2 * po, w + 2 * po), x)
         psum = self._step()
         rows = h * self.npart_
@@ -692,10 +699,13 @@ class EntropyConv2Op(_WavefrontOp):
             if ln > 0:
                 if psum == 0:
                     top.zero_()
+                first = max(psum - self.ngroup_ + 1, 0)
+                end = psum + 1 if psum < rows + w - 2 else rows + w - 1
                 call("pconv_entropy_conv", _ptr(x), _ptr(weight.detach()), _ptr(bias.detach()),
-                     _ptr(act.detach()) if act is not None else None, _ptr(top), _ptr(order), lo, ln, nimg,
-                     max(nimg // nset, 1), channel, self.nout_, self.ngroup_, self.kernel_size_,
-                     self.constrain_, self.npart_, h, w, pi, po, psum, _stream(x.device))
+                     _ptr(act.detach()) if act is not None else None, _ptr(top), _ptr(order), _ptr(start_dev),
+                     first, end - first, longest, nimg, max(nimg // nset, 1), channel, self.nout_, self.ngroup_,
+                     self.kernel_size_, self.constrain_, self.npart_, h, w, pi, po, psum, None, None, None, None,
+                     _stream(x.device))
         return [top]
 
     def forward(self, x, weight, bias):

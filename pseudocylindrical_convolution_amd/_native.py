@@ -46,12 +46,15 @@ _HIP_SIGNATURES = {
     # entropy wavefront
     "pconv_dinput2": [P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "pconv_ctx_pad_run2": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
-    "pconv_entropy_conv": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "pconv_entropy_conv": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, P],
+    "pconv_host_causal_table": [P, I, I, I, I, P, P],
     "pconv_entropy_add": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "pconv_dextract2": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "pconv_dextract2_batch": [P, P, P, I, I, I, I, I, I, I, I, I, I, LL, P],
     "pconv_gmm_table": [P, P, P, P, I, I, I, F, F, F, I, P],
     "pconv_ctx_to_symbols": [P, P, P, I, I, I, I, I, I, F, P],
+    "pconv_symbols_to_ctx": [P, P, P, I, I, I, I, I, I, F, I, P],
+    "pconv_step_tables": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, F, P],
     # native entropy engine
     "pconv_ee_set_layer": [P, I, P, P, P],
     "pconv_ee_steps": [P],

@@ -14,6 +14,7 @@
 //     once; the CPU coder then runs over it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <thread>
@@ -59,17 +60,21 @@ struct pconv_entropy_engine {
   float bias, total, beta;
   int rows, nsteps, cpn;  // cpn = gaussians = outputs per group of the last layer
   std::vector<int32_t> widths, sched_start;
-  int32_t *widths_d = nullptr, *order_d = nullptr;
+  int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr;
+  int32_t *vh_col = nullptr;  // dense causal halo table (pconv_host_causal_table)
+  float *vh_wgt = nullptr;
+  int longest_plane = 0;
+  bool stored_halo = false;  // debugging aid: run EntropyCtxPadRun2 launches instead of virtual halos
   HaloList halo_in, halo_hid;
   const float *lw[kLayers] = {nullptr}, *lb[kLayers] = {nullptr}, *la[kLayers] = {nullptr};
   float *ctx = nullptr;             // (3*nimg*npart, ngroup, h+4, w+4)
   float *act[kLayers] = {nullptr};  // layer outputs, persistent across steps
   float *packed = nullptr;          // symbols of the previous step, [img][len]
-  float *params = nullptr;          // extract_batch sections (3 x stride)
-  float *tables_d = nullptr;        // step tables (decode) / all tables (encode)
-  float *labels_d = nullptr;
-  float *tables_h = nullptr, *labels_h = nullptr, *packed_h = nullptr;  // pinned
-  size_t sym_per_img = 0, max_len = 0, section_stride = 0;
+  int32_t *tables_d = nullptr;      // step tables (decode) / all tables (encode)
+  int32_t *labels_d = nullptr;
+  int32_t *tables_h = nullptr, *labels_h = nullptr;  // pinned
+  float *packed_h = nullptr;                         // pinned
+  size_t sym_per_img = 0, max_len = 0;
   std::vector<std::vector<uint8_t>> streams;
   std::vector<pconv_coder *> coders;
 
@@ -137,12 +142,28 @@ struct pconv_entropy_engine {
     HIP_TRY(hipMemcpy(widths_d, widths.data(), npart * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&order_d, order.size() * 4));
     HIP_TRY(hipMemcpy(order_d, order.data(), order.size() * 4, hipMemcpyHostToDevice));
-    PC_TRY(build_halo(halo_in, ngroup));
-    PC_TRY(build_halo(halo_hid, 3 * ngroup));
+    HIP_TRY(hipMalloc(&sched_start_d, sched_start.size() * 4));
+    HIP_TRY(hipMemcpy(sched_start_d, sched_start.data(), sched_start.size() * 4, hipMemcpyHostToDevice));
+    longest_plane = 0;
+    for (int p = 0; p + 1 < rows + w; p++)
+      if (sched_start[p + 1] - sched_start[p] > longest_plane) longest_plane = sched_start[p + 1] - sched_start[p];
+    {
+      const size_t n = (size_t)npart * 2 * kPad * w;
+      std::vector<int32_t> col(n);
+      std::vector<float> wg(n);
+      PC_TRY(pconv_host_causal_table(widths.data(), npart, h, w, kPad, col.data(), wg.data()));
+      HIP_TRY(hipMalloc(&vh_col, n * 4));
+      HIP_TRY(hipMalloc(&vh_wgt, n * 4));
+      HIP_TRY(hipMemcpy(vh_col, col.data(), n * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(vh_wgt, wg.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    stored_halo = getenv("PCONV_ENGINE_STORED_HALO") != nullptr;
+    if (stored_halo) {
+      PC_TRY(build_halo(halo_in, ngroup));
+      PC_TRY(build_halo(halo_hid, 3 * ngroup));
+    }
     HIP_TRY(hipMalloc(&ctx, ctx_elems() * 4));
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&act[l], act_elems(l) * 4));
-    section_stride = (size_t)cpn * rows * w * nimg;
-    HIP_TRY(hipMalloc(&params, 3 * section_stride * 4));
     HIP_TRY(hipMalloc(&packed, (size_t)nimg * rows * w * 4));
     const size_t all_rows = sym_per_img * nimg;
     HIP_TRY(hipMalloc(&tables_d, all_rows * (nstep_levels + 1) * 4));
@@ -159,7 +180,7 @@ struct pconv_entropy_engine {
     auto freed = [](void *p) {
       if (p) (void)hipFree(p);
     };
-    freed(widths_d); freed(order_d); freed(ctx); freed(params); freed(packed); freed(tables_d); freed(labels_d);
+    freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt); freed(ctx); freed(packed); freed(tables_d); freed(labels_d);
     for (int l = 0; l < kLayers; l++) freed(act[l]);
     for (HaloList *hl : {&halo_in, &halo_hid}) {
       freed(hl->dst); freed(hl->src0); freed(hl->src1); freed(hl->plane); freed(hl->wgt);
@@ -170,55 +191,55 @@ struct pconv_entropy_engine {
     for (pconv_coder *c : coders) pconv_coder_free(c);
   }
 
-  // one wavefront step of the three-headed network; leaves the step's packed GMM
-  // parameters in `params` and returns the window of the step
-  int network_step(int s, Window prev, Window cur, const float *prev_symbols, hipStream_t st) {
-    const int n3 = 3 * nimg;
-    const int hid = 3 * ngroup;
-    if (s == 0) {
-      HIP_TRY(hipMemsetAsync(ctx, 0, ctx_elems() * 4, st));
-      for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(act[l], 0, act_elems(l) * 4, st));
-    } else if (prev.len > 0) {
-      PC_TRY(pconv_dinput2(prev_symbols, ctx, order_d, prev.lo, prev.len, nimg, ngroup, npart, h, w, kPad, s - 1,
-                           -bias, 3, st));
-    }
-    for (int l = 0; l < kLayers; l++) {
-      float *in = (l == 0) ? ctx : act[l - 1];
-      const HaloList &hl = (l == 0) ? halo_in : halo_hid;
-      const int channel = (l == 0) ? ngroup : hid;
-      const int psum_pad = (l == 0) ? s - 1 : s;  // the input layer lags one step
-      Window hw = halo_window(hl, psum_pad);
-      if (hw.len > 0)
-        PC_TRY(pconv_ctx_pad_run2(in, hl.dst, hl.src0, hl.src1, hl.wgt, hl.plane, hw.lo, hw.len, n3,
-                                  channel / ngroup, channel, npart, h, w, kPad, psum_pad, st));
-      if (cur.len > 0) {
-        PC_TRY(pconv_entropy_conv(in, lw[l], lb[l], la[l], act[l], order_d, cur.lo, cur.len, n3, nimg, channel,
-                                  hid, ngroup, kKernel, l == 0 ? 5 : 6, npart, h, w, kPad,
-                                  l == kLayers - 1 ? 0 : kPad, s, st));
-        if (l >= 2 && l <= 10 && (l % 2) == 0)  // second conv of a residual block: += block input
-          PC_TRY(pconv_entropy_add(act[l], act[l - 2], order_d, cur.lo, cur.len, n3, hid, ngroup, npart, h, w,
-                                   kPad, s, st));
-      }
-    }
-    if (cur.len > 0)
-      PC_TRY(pconv_dextract2_batch(act[kLayers - 1], params, order_d, cur.lo, cur.len, n3, hid, cpn, npart, h, w,
-                                   s, nimg, (long long)section_stride, st));
+  int clear(hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(ctx, 0, ctx_elems() * 4, st));
+    for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(act[l], 0, act_elems(l) * 4, st));
     return PCONV_OK;
   }
 
-  int step_tables(Window cur, float *table_out, hipStream_t st) {
+  // one wavefront step of the three-headed network.  prev_symbols != NULL: scatter
+  // the previous step's symbols first (decoder); the encoder fills ctx up front.
+  int network_step(int s, Window prev, Window cur, const float *prev_symbols, hipStream_t st) {
+    const int n3 = 3 * nimg;
+    const int hid = 3 * ngroup;
+    if (s > 0 && prev.len > 0 && prev_symbols)
+      PC_TRY(pconv_dinput2(prev_symbols, ctx, order_d, prev.lo, prev.len, nimg, ngroup, npart, h, w, kPad, s - 1,
+                           -bias, 3, st));
+    const int first = s - ngroup + 1 < 0 ? 0 : s - ngroup + 1;
+    const int end = s < rows + w - 2 ? s + 1 : rows + w - 1;
+    for (int l = 0; l < kLayers; l++) {
+      float *in = (l == 0) ? ctx : act[l - 1];
+      const int channel = (l == 0) ? ngroup : hid;
+      if (stored_halo) {
+        const HaloList &hl = (l == 0) ? halo_in : halo_hid;
+        const int psum_pad = (l == 0) ? s - 1 : s;  // the input layer lags one step
+        Window hw = halo_window(hl, psum_pad);
+        if (hw.len > 0)
+          PC_TRY(pconv_ctx_pad_run2(in, hl.dst, hl.src0, hl.src1, hl.wgt, hl.plane, hw.lo, hw.len, n3,
+                                    channel / ngroup, channel, npart, h, w, kPad, psum_pad, st));
+      }
+      if (cur.len > 0) {
+        // second conv of a residual block: += block input, folded into the epilogue
+        const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? act[l - 2] : nullptr;
+        PC_TRY(pconv_entropy_conv(in, lw[l], lb[l], la[l], act[l], order_d, sched_start_d, first, end - first,
+                                  longest_plane, n3, nimg, channel, hid, ngroup, kKernel, l == 0 ? 5 : 6, npart,
+                                  h, w, kPad, l == kLayers - 1 ? 0 : kPad, s, res,
+                                  stored_halo ? nullptr : widths_d, stored_halo ? nullptr : vh_col,
+                                  stored_halo ? nullptr : vh_wgt, st));
+      }
+    }
+    return PCONV_OK;
+  }
+
+  int step_tables(int s, Window cur, const float *symbols, int32_t *table_out, int32_t *labels_out,
+                  hipStream_t st) {
     if (cur.len <= 0) return PCONV_OK;
-    return pconv_gmm_table(params, params + section_stride, params + 2 * section_stride, table_out,
-                           cur.len * nimg, cpn, nstep_levels, bias, total, beta, 1, st);
+    return pconv_step_tables(act[kLayers - 1], symbols, table_out, labels_out, order_d, cur.lo, cur.len, nimg,
+                             ngroup, npart, h, w, s, nstep_levels, bias, total, beta, st);
   }
 };
 
 namespace {
-
-// float rows holding integers -> int32 rows for the coder
-void rows_to_i32(const float *src, int32_t *dst, size_t n) {
-  for (size_t i = 0; i < n; i++) dst[i] = (int32_t)src[i];
-}
 
 template <typename Fn>
 void for_each_image(int nimg, Fn fn) {
@@ -280,17 +301,17 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
   for (int l = 0; l < kLayers; l++) PCONV_REQUIRE(e->lw[l], "ee_encode: layer %d has no weights", l);
   hipStream_t st = as_stream(stream);
   const int cols = e->nstep_levels + 1;
+  PC_TRY(e->clear(st));
+  PC_TRY(pconv_symbols_to_ctx(symbols, e->ctx, e->widths_d, e->nimg * e->npart, e->ngroup, e->h, e->w, kPad,
+                              e->npart, -e->bias, 3, st));
   Window prev = {0, 0};
   size_t row = 0;  // rows are laid out [step][img][l]
   std::vector<size_t> step_row(e->nsteps + 1, 0);
   for (int s = 0; s < e->nsteps; s++) {
     Window cur = e->sched_window(s);
     step_row[s] = row;
-    PC_TRY(e->network_step(s, prev, cur, s > 0 ? e->labels_d + step_row[s - 1] : nullptr, st));
-    PC_TRY(e->step_tables(cur, e->tables_d + row * cols, st));
-    if (cur.len > 0)  // labels of this step, packed [img][l]; they are also next step's input
-      PC_TRY(pconv_dextract2(symbols, e->labels_d + row, e->order_d, cur.lo, cur.len, e->nimg, e->ngroup, 1,
-                             e->npart, e->h, e->w, s, st));
+    PC_TRY(e->network_step(s, prev, cur, nullptr, st));
+    PC_TRY(e->step_tables(s, cur, symbols, e->tables_d + row * cols, e->labels_d + row, st));
     row += (size_t)cur.len * e->nimg;
     prev = cur;
   }
@@ -301,17 +322,12 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
   int status = 0;
   for_each_image(e->nimg, [&](int img) {
     pconv_coder *c = e->coders[img];
-    std::vector<int32_t> tab, lab;
     int rc = pconv_coder_start_encoder(c);
     for (int s = 0; s < e->nsteps && rc >= 0; s++) {
       const size_t len = (step_row[s + 1] - step_row[s]) / e->nimg;
       if (!len) continue;
       const size_t r0 = step_row[s] + (size_t)img * len;
-      tab.resize(len * cols);
-      lab.resize(len);
-      rows_to_i32(e->tables_h + r0 * cols, tab.data(), len * cols);
-      rows_to_i32(e->labels_h + r0, lab.data(), len);
-      rc = pconv_coder_encodes(c, tab.data(), e->nstep_levels, lab.data(), (int)len);
+      rc = pconv_coder_encodes(c, e->tables_h + r0 * cols, e->nstep_levels, e->labels_h + r0, (int)len);
     }
     if (rc >= 0) rc = pconv_coder_end_encoder(c);
     if (rc < 0) {
@@ -345,23 +361,22 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
       pconv_set_error("ee_decode: cannot start decoder %d", i);
       return PCONV_EINVAL;
     }
+  PC_TRY(e->clear(st));
   Window prev = {0, 0};
-  std::vector<int32_t> tab, sym;
+  std::vector<int32_t> sym;
   int status = 0;
   for (int s = 0; s < e->nsteps; s++) {
     Window cur = e->sched_window(s);
     PC_TRY(e->network_step(s, prev, cur, e->packed, st));
     if (cur.len > 0) {
       const size_t rows = (size_t)cur.len * e->nimg;
-      PC_TRY(e->step_tables(cur, e->tables_d, st));
+      PC_TRY(e->step_tables(s, cur, nullptr, e->tables_d, nullptr, st));
       HIP_TRY(hipMemcpyAsync(e->tables_h, e->tables_d, rows * cols * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      tab.resize(rows * cols);
       sym.resize(rows);
-      rows_to_i32(e->tables_h, tab.data(), rows * cols);
       for_each_image(e->nimg, [&](int img) {
-        int rc = pconv_coder_decodes_i32(e->coders[img], tab.data() + (size_t)img * cur.len * cols, e->nstep_levels,
-                                         sym.data() + (size_t)img * cur.len, cur.len);
+        int rc = pconv_coder_decodes_i32(e->coders[img], e->tables_h + (size_t)img * cur.len * cols,
+                                         e->nstep_levels, sym.data() + (size_t)img * cur.len, cur.len);
         if (rc < 0) status = rc;
       });
       if (status < 0) {

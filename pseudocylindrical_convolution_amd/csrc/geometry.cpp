@@ -196,7 +196,50 @@ struct HaloEntry {
   int32_t plane, dst, src0, src1;
   float wgt;
 };
+
+// Causal version of the facing-column rule (entropy_context_cuda.cu:141-157):
+// column i of a tile of width wfrom looks at columns c, c+1 of the neighbouring
+// tile (width wto) with weights w, 1-w, clamped so that only already-coded
+// columns contribute.  Returns false when nothing is visible yet.
+inline bool causal_columns(int i, int wfrom, int wto, int *c_out, float *w_out) {
+  float p = facing_column(i, wfrom, wto, false);
+  int c = p < 0 ? -1 : static_cast<int>(p);
+  float w;
+  if (c > i) return false;
+  if (c + 1 > i) {
+    w = 1.f;
+  } else {
+    w = c + 1 - p;
+    if (c == -1) w = 0.f;
+  }
+  *c_out = c;
+  *w_out = w;
+  return true;
+}
 }  // namespace
+
+extern "C" int pconv_host_causal_table(const int32_t *widths, int npart, int height, int width, int pad,
+                                       int32_t *col, float *wgt) {
+  PCONV_REQUIRE(widths && col && wgt && pad >= 1, "causal_table: bad argument");
+  const int rows = height * npart;
+  for (int t = 0; t < npart; t++)
+    for (int side = 0; side < 2; side++)
+      for (int r = 0; r < pad; r++) {
+        const int row = (side == 0) ? t * height - pad + r : (t + 1) * height + r;
+        const size_t base = ((size_t)(t * 2 + side) * pad + r) * width;
+        for (int i = 0; i < width; i++) {
+          col[base + i] = -2;
+          wgt[base + i] = 0.f;
+          if (row < 0 || row >= rows || i >= widths[t]) continue;
+          int c;
+          float w;
+          if (!causal_columns(i, widths[t], widths[row / height], &c, &w)) continue;
+          col[base + i] = c;
+          wgt[base + i] = w;
+        }
+      }
+  return PCONV_OK;
+}
 
 extern "C" int pconv_host_causal_halo(const int32_t *widths, int npart, int channel,
                                       int height, int width, int pad, int32_t *dst,
@@ -222,16 +265,9 @@ extern "C" int pconv_host_causal_halo(const int32_t *widths, int npart, int chan
         const int32_t dbase = (int32_t)(t * tile_stride + (long long)drow * pw);
         const int32_t sbase = (int32_t)(st * tile_stride + (long long)(pad + row % height) * pw);
         for (int i = 0; i < widths[t]; i++) {
-          float p = facing_column(i, widths[t], widths[st], false);
-          int c = p < 0 ? -1 : static_cast<int>(p);
+          int c;
           float w;
-          if (c > i) continue;  // source not coded yet: halo stays zero
-          if (c + 1 > i) {
-            w = 1.f;
-          } else {
-            w = c + 1 - p;
-            if (c == -1) w = 0.f;
-          }
+          if (!causal_columns(i, widths[t], widths[st], &c, &w)) continue;  // halo stays zero
           HaloEntry e;
           e.plane = row + i;
           e.dst = dbase + i + pad;
