@@ -289,9 +289,10 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
                                       float beta);
 void pconv_ee_destroy(pconv_entropy_engine *e);
 /* layer 0..11 = net.0.conv, net.1.conv1.conv, net.1.conv2.conv, ..., net.6.conv;
- * device pointers: weight (3, 3G, cin, 5, 5), bias (3, 3G), slope (3, 3G) or NULL */
+ * device pointers: weight (3, 3G, cin, 5, 5), bias (3, 3G), slope (3, 3G) or NULL.
+ * The weight is copied (re-packed) on `stream`; bias and slope are borrowed. */
 int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, const float *bias,
-                       const float *slope);
+                       const float *slope, void *stream);
 long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e);
 int pconv_ee_steps(const pconv_entropy_engine *e);
 /* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */

@@ -863,7 +863,7 @@ void orc_ctx_pad_run2(float *data, const i64 *dstoff, const i64 *srcoff, const i
  *            25*group_in, each looping over the allowed groups; shared-memory
  *            halving 128->64->32, then shuffle-down 16..1);
  * order = 1: the product's published order (64 lanes striding over the flattened
- *            (ci,kh,kw) index with fmaf, xor-butterfly 32..1). */
+ *            tap-major index kk = (kh*5+kw)*cin + ci with fmaf, xor-butterfly 32..1). */
 static float reduce_ref128(float *s) {
   for (int t = 0; t < 64; t++) s[t] = s[t] + s[t + 64];
   for (int t = 0; t < 32; t++) s[t] = s[t] + s[t + 32];
@@ -933,15 +933,16 @@ void orc_entropy_conv(const float *input, const float *weight, const float *bias
       for (int lane = 0; lane < 64; lane++) {
         float s = 0;
         for (int kk = lane; kk < red; kk += 64) {
-          int kw = kk % kernel_size;
-          int kh = (kk / kernel_size) % kernel_size;
-          int ci = kk / skernel;
+          int ci = kk % channel;
+          int tap = kk / channel;
+          int kw = tap % kernel_size;
+          int kh = tap / kernel_size;
           int qh = hp - half_kernel + kh;
           int pw = tw - half_kernel + kw;
           int nchannel = constrain == 5 ? (psum - qh - pw) * group_in : (psum - qh - pw + 1) * group_in;
           if (ci < nchannel) {
             i64 d = ((i64)qn * channel + ci) * index_stride + (i64)(th - half_kernel + kh + pad_in) * (width + 2 * pad_in) + pw + pad_in;
-            s = fmaf(input[d], wrow[kk], s);
+            s = fmaf(input[d], wrow[ci * skernel + tap], s);
           }
         }
         part[lane] = s;

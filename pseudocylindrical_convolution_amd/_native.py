@@ -56,7 +56,7 @@ _HIP_SIGNATURES = {
     "pconv_symbols_to_ctx": [P, P, P, I, I, I, I, I, I, F, I, P],
     "pconv_step_tables": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, F, P],
     # native entropy engine
-    "pconv_ee_set_layer": [P, I, P, P, P],
+    "pconv_ee_set_layer": [P, I, P, P, P, P],
     "pconv_ee_steps": [P],
     "pconv_ee_encode": [P, P, P],
     "pconv_ee_decode": [P, P, P, P, P],

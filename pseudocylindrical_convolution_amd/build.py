@@ -25,6 +25,7 @@ HIP_SOURCES = [
     "tilepad.hip",
     "pointwise.hip",
     "entropy.hip",
+    "entropy_engine.hip",
     "conv.hip",
     "engine.cpp",
     "coder.cpp",  # the engine drives the arithmetic coder natively
@@ -87,6 +88,10 @@ def build(verbose=False, jobs=4):
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     hdr = _newest_header()
+    extra = os.environ.get("PCONV_EXTRA_HIPFLAGS", "").split()  # tuning experiments only
+    if extra:
+        HIP_FLAGS.extend(extra)
+        hdr = float("inf")  # force a rebuild with the extra flags
     sources = [s for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         res = list(ex.map(lambda s: _compile(s, HIP_FLAGS, cc, hdr, True), sources))

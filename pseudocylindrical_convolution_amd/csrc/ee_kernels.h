@@ -1,0 +1,45 @@
+// Private interface between the native entropy engine (engine.cpp) and its
+// channels-last kernels (entropy_engine.hip).  Not part of the public C ABI.
+//
+// Layout inside the engine ("tile-HWC"): a tensor with C channels is stored as
+//   [image*npart + tile][row (+pad)][col (+pad)][C]
+// so that the 5 x 5 x C window of a position is 5 runs of 5*C contiguous floats.
+// The per-op API (include/pconv_hip.h) keeps the reference's NCHW.
+#pragma once
+#include <stdint.h>
+
+struct EeGeom {
+  int npart, ngroup, h, w;  // tiles, channel groups, rows per tile, columns
+  int nimg;                 // frames in lock-step (the network runs 3*nimg replicas)
+  const int32_t *widths;    // device, valid width per tile
+  const int32_t *order, *plane_start;  // device, wavefront schedule
+  const int32_t *vh_col;    // device, dense causal halo table
+  const float *vh_wgt;
+  // per reduction index kk = tap*cin + ci, for cin = ngroup ([0]) and 3*ngroup ([1]):
+  //   tap_off  element offset of the tap from the window origin
+  //   tap_lim  (4 - kh - kw)*group_in - ci; the tap is causal iff tap_lim + (tc + slack)*group_in > 0
+  //   tap_pos  kh | kw << 4 | ci << 8 (for the halo path)
+  const int32_t *tap_off[2], *tap_lim[2], *tap_pos[2];
+};
+
+// weights (3, cout, cin, 5, 5) -> (3, cout, 25*cin) in reduction order tap*cin + ci
+int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, void *stream);
+
+// one layer of one step.  x: cin channels, padded by 2; y: cout channels, padded
+// by pad_out.  shared_input: x holds nimg images that every replica reads
+// (layer 0), otherwise 3*nimg.  Output group of plane p is psum - p.
+int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
+            const float *slope, const float *residual, float *y, int cin, int cout, int constrain,
+            int pad_out, int first_plane, int nplane, int longest_plane, int psum, void *stream);
+
+// decoder: symbols of one step (packed [img][l]) + bias into ctx (nimg images)
+int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,
+               void *stream);
+// encoder: all symbols (NCHW float indices) + bias into a zeroed ctx
+int ee_fill_ctx(const EeGeom *g, const float *symbols, float *ctx, float bias, void *stream);
+// decoder epilogue: ctx -> NCHW symbols (index = value - bias), zero in dead columns
+int ee_read_symbols(const EeGeom *g, const float *ctx, float *symbols, float bias, void *stream);
+// integer CDF rows of one step from the last layer's output (unpadded, 3*ngroup
+// channels); optional labels from the NCHW symbol tensor
+int ee_tables(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
+              int lo, int len, int psum, int nstep, float bias, float total, float beta, void *stream);

@@ -11,6 +11,7 @@
 // entropy_gmm_table_cuda.cu.
 #include "common.h"
 #include "../../include/pconv_detmath.h"
+#include "gmm_device.h"
 
 namespace {
 
@@ -166,10 +167,12 @@ __global__ __launch_bounds__(kBlock) void dextract2_kernel(
 // image, one per wave; they share the output group (tc = psum - plane) and
 // therefore the GO x (cin*25) weight rows, which are staged in LDS once per
 // workgroup while the gathers are in flight.  Lanes stride over the flattened
-// reduction index kk = (ci*5 + kh)*5 + kw, keep GO partial sums and finish with a
-// butterfly.  Reduction order (part of the bitstream contract, restated by the
-// oracle): lane l accumulates kk = l, l+64, ... with fmaf, skipping taps the
-// causal mask forbids, then v += shfl_xor(v, 32, 16, 8, 4, 2, 1).
+// reduction index kk = (kh*5 + kw)*cin + ci (tap-major, channel-minor: the order
+// in which the engine's channels-last buffers are contiguous), keep GO partial
+// sums and finish with a butterfly.  Reduction order (part of the bitstream
+// contract, restated by the oracle): lane l accumulates kk = l, l+64, ... with
+// fmaf, skipping taps the causal mask forbids, then
+// v += shfl_xor(v, 32, 16, 8, 4, 2, 1).
 // All ITER gathers of a lane are issued before the first fmaf (the step is
 // latency-bound); weights come from LDS (consecutive lanes, conflict-free).
 //
@@ -217,8 +220,12 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
   // issue both before anything waits
   const int hw = order[lo + (active ? pi : first)];
   {
+    // LDS copy in reduction order: wl[o][tap*cin + ci] = W[o][ci][tap]
     const float *wrow = weight + ((size_t)set * cout + tc * GO) * red;
-    for (int i = threadIdx.x; i < GO * red; i += kConvBlock) wl[i] = wrow[i];
+    for (int i = threadIdx.x; i < GO * red; i += kConvBlock) {
+      const int o = i / red, kk = i - o * red;
+      wl[i] = wrow[o * red + (kk % cin) * KK + kk / cin];
+    }
   }
   const Pos p = decode_pos(hw, h, w);
   const int hin = h + 2 * pad_in, win = w + 2 * pad_in;
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
     for (int it = 0; it < ITER; it++) {
       const int kk = lane + it * kWave;
       const int kc = kk < red ? kk : red - 1;
-      const int kw = kc % K, kh = (kc / K) % K, ci = kc / KK;
+      const int ci = kc % cin, tap = kc / cin;
+      const int kw = tap % K, kh = tap / K;
       // causality: input group g at (qh, pw) is usable iff g + qh + pw < psum
       // (constrain 5) or <= psum (constrain 6); qh + pw = row + tw - 4 + kh + kw
       const int nch = (tc + 2 * HALF - kh - kw + slack) * group_in;
@@ -257,7 +265,8 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
     for (int it = 0; it < ITER; it++) {
       const int kk = lane + it * kWave;
       const int kc = kk < red ? kk : red - 1;
-      const int kw = kc % K, kh = (kc / K) % K, ci = kc / KK;
+      const int ci = kc % cin, tap = kc / cin;
+      const int kw = tap % K, kh = tap / K;
       const int nch = (tc + 2 * HALF - kh - kw + slack) * group_in;
       ok[it] = active && (kk < red) && (ci < nch);
       src_off[it] = -1;
@@ -334,65 +343,6 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
     if (residual) v = v + residual[oidx];  // EntropyAdd folded in (entropy_add_cuda.cu:42)
     y[oidx] = v;
   }
-}
-
-// ---- GMM -> integer CDF row (entropy_gmm_table_cuda.cu:29-57,83-105,136-153) ----
-constexpr int kMaxGauss = 16;
-
-// softmax over the mixture weights and delta = max(delta, 0) + beta, on registers
-__device__ __forceinline__ void gmm_prepare_row(float *wt, float *dl, int ng, float beta) {
-  float mval = -1e10, psum = 0;
-  for (int k = 0; k < ng; k++)
-    if (mval < wt[k]) mval = wt[k];
-  for (int k = 0; k < ng; k++) {
-    wt[k] = pconv_expf(wt[k] - mval);
-    psum += wt[k];
-  }
-  for (int k = 0; k < ng; k++) {
-    wt[k] = wt[k] / psum;
-    dl[k] = dl[k] < 0 ? beta : dl[k] + beta;
-  }
-}
-
-// row[0..nstep]: integer CDF with the reference's monotonicity repair applied on
-// the fly (every bin at least one count, taken back from the widest bin)
-template <typename Out>
-__device__ __forceinline__ void gmm_cdf_row(const float *wt, const float *dl, const float *mu, int ng,
-                                            int nstep, float bias, float total, int batch_arith,
-                                            Out *row) {
-  const float s2 = 1. / sqrt(2.0);
-  float prev = 0.f, shift = 0.f, widest = 0.f;
-  int widest_at = 0;
-  row[0] = (Out)0;
-  for (int pt = 1; pt <= nstep; pt++) {
-    float cur;
-    if (pt == nstep) {
-      cur = static_cast<int>(total);
-    } else {
-      float v = pt - 1 - bias + 0.5, ps = 0;
-      for (int k = 0; k < ng; k++) {
-        const float e = pconv_erff(s2 * (v - mu[k]) / dl[k]);
-        if (batch_arith) {
-          ps = ps + wt[k] * (0.5 + 0.5 * e);  // double inside, as :148
-        } else {
-          const float f = 0.5 + 0.5 * e;  // rounded to float, as :72-73
-          ps = ps + wt[k] * f;
-        }
-      }
-      cur = static_cast<int>(total * ps + 0.5);
-    }
-    // check kernel: compares the raw entry with the already shifted previous one
-    if (cur <= prev) shift += 1;
-    cur += shift;
-    if (cur - prev > widest) {
-      widest = cur - prev;
-      widest_at = pt - 1;
-    }
-    row[pt] = (Out)cur;
-    prev = cur;
-  }
-  if (shift > 0)
-    for (int pt = widest_at; pt < nstep; pt++) row[pt + 1] = (Out)((float)row[pt + 1] - shift);
 }
 
 // PCONV.EntropyGmmTableOp: parameters in three packed arrays, modified in place

@@ -54,8 +54,10 @@ class EntropyEngine(object):
                     t = t.to(self.device, torch.float32).contiguous()
                 held.append(t)
             self._params.append(held)
-            call("pconv_ee_set_layer", self.handle, layer, held[0].data_ptr(), held[1].data_ptr(),
-                 held[2].data_ptr() if held[2] is not None else None)
+            with torch.cuda.device(self.device):
+                call("pconv_ee_set_layer", self.handle, layer, held[0].data_ptr(), held[1].data_ptr(),
+                     held[2].data_ptr() if held[2] is not None else None,
+                     torch.cuda.current_stream(self.device).cuda_stream)
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -115,12 +117,16 @@ class CodecEngine(object):
 
     @torch.no_grad()
     def symbols(self, frames):
-        """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero"""
-        sym = self.enc.symbols(frames)
-        return self.enc.ent.fill(sym)
+        """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero.
+        The analysis transform runs frame by frame (its activations are GBs at
+        4096x2048); only the small symbol tensors are batched."""
+        per_frame = [self.enc.ent.fill(self.enc.symbols(frames[i:i + 1])).clone() for i in range(frames.shape[0])]
+        return per_frame[0] if len(per_frame) == 1 else torch.cat(per_frame, 0)
 
     @torch.no_grad()
     def encode(self, frames):
+        """(n, 3, H, W) frames on the GPU -> n byte strings; the n frames go through
+        the entropy wavefront in lock-step"""
         sym = self.symbols(frames)
         eng = self._engine("enc", sym.shape[2], sym.shape[3], frames.shape[0])
         return eng.encode(sym.contiguous())
@@ -128,5 +134,8 @@ class CodecEngine(object):
     @torch.no_grad()
     def decode(self, streams, height, width):
         h, w = PC.latent_shape(height, width, self.dec.npart)
-        eng = self._engine("dec", 2 * h, 2 * w, len(streams))
-        return self.dec.reconstruct(eng.decode(streams))
+        n = len(streams)
+        sym = self._engine("dec", 2 * h, 2 * w, n).decode(streams)
+        tiles = self.dec.npart
+        out = [self.dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(n)]
+        return out[0] if n == 1 else torch.cat(out, 0)
