@@ -20,7 +20,15 @@ struct EeGeom {
   //   tap_lim  (4 - kh - kw)*group_in - ci; the tap is causal iff tap_lim + (tc + slack)*group_in > 0
   //   tap_pos  kh | kw << 4 | ci << 8 (for the halo path)
   const int32_t *tap_off[2], *tap_lim[2], *tap_pos[2];
+  // bulk (encoder) mode: every (plane, group) pair at once
+  const int32_t *bulk_wg;    // device, (plane, first position) per workgroup of kBulkPos positions
+  int nbulk_wg;
+  const int32_t *pos_plane;  // device, plane of every schedule entry
+  const int32_t *step_row;   // device, first table row of every step (rows are [step][img][l])
+  int npos;
 };
+
+constexpr int kEeBulkPos = 8;  // positions per workgroup in bulk mode
 
 // weights (3, cout, cin, 5, 5) -> (3, cout, 25*cin) in reduction order tap*cin + ci
 int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, void *stream);
@@ -31,6 +39,14 @@ int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, v
 int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
             const float *slope, const float *residual, float *y, int cin, int cout, int constrain,
             int pad_out, int first_plane, int nplane, int longest_plane, int psum, void *stream);
+// the same layer for ALL (plane, group) pairs at once (encoder: every symbol is
+// known, the causal masks make each output equal to the step-by-step one)
+int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
+                 const float *slope, const float *residual, float *y, int cin, int cout, int constrain,
+                 int pad_out, void *stream);
+// CDF rows and labels of all symbols, written in stream order
+int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
+                   int nstep, float bias, float total, float beta, void *stream);
 
 // decoder: symbols of one step (packed [img][l]) + bias into ctx (nimg images)
 int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,

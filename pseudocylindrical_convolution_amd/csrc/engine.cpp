@@ -72,6 +72,9 @@ struct pconv_entropy_engine {
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
   float *vh_wgt = nullptr;
   int32_t *tap_tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int32_t *bulk_wg_d = nullptr, *pos_plane_d = nullptr, *step_row_d = nullptr;
+  std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
+  bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
   const float *lb[kLayers] = {nullptr}, *la[kLayers] = {nullptr};
   bool bound[kLayers] = {false};
@@ -129,7 +132,7 @@ struct pconv_entropy_engine {
       HIP_TRY(hipMemcpy(vh_wgt, wg.data(), n * 4, hipMemcpyHostToDevice));
     }
     geom = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, {nullptr, nullptr},
-            {nullptr, nullptr}, {nullptr, nullptr}};
+            {nullptr, nullptr}, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, 0};
     for (int tt = 0; tt < 2; tt++) {  // tap tables for cin = G and cin = 3G
       const int cin = tt == 0 ? ngroup : 3 * ngroup, group_in = cin / ngroup, red = cin * 25;
       std::vector<int32_t> off(red), lim(red), pos(red);
@@ -147,6 +150,32 @@ struct pconv_entropy_engine {
       geom.tap_off[tt] = tap_tab[tt][0];
       geom.tap_lim[tt] = tap_tab[tt][1];
       geom.tap_pos[tt] = tap_tab[tt][2];
+    }
+    {  // bulk (encoder) maps
+      const int npos = sched_start[rows + w - 1];
+      std::vector<int32_t> wg, pp(npos);
+      for (int p = 0; p + 1 < rows + w; p++) {
+        const int cnt = sched_start[p + 1] - sched_start[p];
+        for (int i = 0; i < cnt; i++) pp[sched_start[p] + i] = p;
+        for (int f = 0; f < cnt; f += kEeBulkPos) {
+          wg.push_back(p);
+          wg.push_back(f);
+        }
+      }
+      step_row.assign(nsteps + 1, 0);
+      for (int s = 0; s < nsteps; s++) step_row[s + 1] = step_row[s] + window(s).len * nimg;
+      HIP_TRY(hipMalloc(&bulk_wg_d, wg.size() * 4));
+      HIP_TRY(hipMemcpy(bulk_wg_d, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&pos_plane_d, pp.size() * 4));
+      HIP_TRY(hipMemcpy(pos_plane_d, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&step_row_d, step_row.size() * 4));
+      HIP_TRY(hipMemcpy(step_row_d, step_row.data(), step_row.size() * 4, hipMemcpyHostToDevice));
+      geom.bulk_wg = bulk_wg_d;
+      geom.nbulk_wg = (int)(wg.size() / 2);
+      geom.pos_plane = pos_plane_d;
+      geom.step_row = step_row_d;
+      geom.npos = npos;
+      stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
     }
     HIP_TRY(hipMalloc(&ctx, ctx_elems() * 4));
     for (int l = 0; l < kLayers; l++) {
@@ -171,6 +200,7 @@ struct pconv_entropy_engine {
     };
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
     freed(ctx); freed(packed); freed(tables_d); freed(labels_d);
+    freed(bulk_wg_d); freed(pos_plane_d); freed(step_row_d);
     for (int tt = 0; tt < 2; tt++)
       for (int a = 0; a < 3; a++) freed(tap_tab[tt][a]);
     for (int l = 0; l < kLayers; l++) {
@@ -200,6 +230,18 @@ struct pconv_entropy_engine {
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? act[l - 2] : nullptr;
       PC_TRY(ee_conv(&geom, in, l == 0, lw[l], lb[l], la[l], res, act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
                      l == kLayers - 1 ? 0 : kPad, cur.first, cur.nplane, longest_plane, s, st));
+    }
+    return PCONV_OK;
+  }
+
+  // every layer once over all (plane, group) pairs: the encoder knows all symbols
+  int network_bulk(hipStream_t st) {
+    const int hid = 3 * ngroup;
+    for (int l = 0; l < kLayers; l++) {
+      const float *in = (l == 0) ? ctx : act[l - 1];
+      const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? act[l - 2] : nullptr;
+      PC_TRY(ee_conv_bulk(&geom, in, l == 0, lw[l], lb[l], la[l], res, act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
+                          l == kLayers - 1 ? 0 : kPad, st));
     }
     return PCONV_OK;
   }
@@ -257,17 +299,20 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
   // step from seeing more than DInput2 would have given it
   PC_TRY(e->clear(st));
   PC_TRY(ee_fill_ctx(&e->geom, symbols, e->ctx, -e->bias, st));
-  size_t row = 0;  // rows are laid out [step][img][l]
-  std::vector<size_t> step_row(e->nsteps + 1, 0);
-  for (int s = 0; s < e->nsteps; s++) {
-    const Window cur = e->window(s);
-    step_row[s] = row;
-    PC_TRY(e->network_step(s, cur, st));
-    PC_TRY(ee_tables(&e->geom, e->act[kLayers - 1], symbols, e->tables_d + row * cols, e->labels_d + row, cur.lo,
-                     cur.len, s, e->nlevels, e->bias, e->total, e->beta, st));
-    row += (size_t)cur.len * e->nimg;
+  const std::vector<int32_t> &step_row = e->step_row;  // rows are laid out [step][img][l]
+  const size_t row = step_row[e->nsteps];
+  if (e->stepwise_encoder) {
+    for (int s = 0; s < e->nsteps; s++) {
+      const Window cur = e->window(s);
+      PC_TRY(e->network_step(s, cur, st));
+      PC_TRY(ee_tables(&e->geom, e->act[kLayers - 1], symbols, e->tables_d + (size_t)step_row[s] * cols,
+                       e->labels_d + step_row[s], cur.lo, cur.len, s, e->nlevels, e->bias, e->total, e->beta, st));
+    }
+  } else {
+    PC_TRY(e->network_bulk(st));
+    PC_TRY(ee_tables_bulk(&e->geom, e->act[kLayers - 1], symbols, e->tables_d, e->labels_d, e->nlevels, e->bias,
+                          e->total, e->beta, st));
   }
-  step_row[e->nsteps] = row;
   HIP_TRY(hipMemcpyAsync(e->tables_h, e->tables_d, row * cols * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(e->labels_h, e->labels_d, row * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -276,9 +321,9 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
     pconv_coder *c = e->coders[img];
     int rc = pconv_coder_start_encoder(c);
     for (int s = 0; s < e->nsteps && rc >= 0; s++) {
-      const size_t len = (step_row[s + 1] - step_row[s]) / e->nimg;
+      const size_t len = (size_t)(step_row[s + 1] - step_row[s]) / e->nimg;
       if (!len) continue;
-      const size_t r0 = step_row[s] + (size_t)img * len;
+      const size_t r0 = (size_t)step_row[s] + (size_t)img * len;
       rc = pconv_coder_encodes(c, e->tables_h + r0 * cols, e->nlevels, e->labels_h + r0, (int)len);
     }
     if (rc >= 0) rc = pconv_coder_end_encoder(c);

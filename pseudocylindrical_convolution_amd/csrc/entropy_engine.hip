@@ -25,7 +25,7 @@ constexpr int kWave = 64;
 #define EE_WAVES_PER_EU 1
 #endif
 constexpr int kConvBlock = EE_CONV_BLOCK;  // one wavefront position per wave
-constexpr int kPosPerWg = kConvBlock / kWave;
+constexpr int kBulkBlock = kEeBulkPos * kWave;
 constexpr int K = 5, KK = 25, HALF = 2, PAD = 2, GO = 3;
 
 struct Pos {
@@ -48,23 +48,36 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
   packed[i] = w[(size_t)row * red + (kk % cin) * KK + kk / cin];
 }
 
-template <int CIN, int ITER>
-__global__ __launch_bounds__(kConvBlock, EE_WAVES_PER_EU) void ee_conv_kernel(
+// BLOCK threads = BLOCK/64 positions per workgroup.  BULK: blockIdx enumerates
+// (workgroup of the bulk map, group, image) and psum = plane + group.
+template <int CIN, int ITER, int BLOCK, bool BULK>
+__global__ __launch_bounds__(BLOCK, EE_WAVES_PER_EU) void ee_conv_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
     float *__restrict__ y, int cout, int constrain, int pad_out, int first_plane, int nplane, int chunks,
     int psum) {
   constexpr int RED = CIN * KK;
+  constexpr int kPosPerWg = BLOCK / kWave;
   __shared__ float wl[GO * RED];
-  const int chunk = blockIdx.x % chunks;
-  const int pl = (blockIdx.x / chunks) % nplane;
-  const int pn = blockIdx.x / chunks / nplane;  // replica-major image index, 0 .. 3*nimg
-  const int plane = first_plane + pl;
+  int plane, first, pn, tc;
+  if (BULK) {
+    const int wg = blockIdx.x % g.nbulk_wg;
+    tc = (blockIdx.x / g.nbulk_wg) % g.ngroup;
+    pn = blockIdx.x / g.nbulk_wg / g.ngroup;
+    plane = g.bulk_wg[2 * wg];
+    first = g.bulk_wg[2 * wg + 1];
+    psum = plane + tc;
+  } else {
+    const int chunk = blockIdx.x % chunks;
+    const int pl = (blockIdx.x / chunks) % nplane;
+    pn = blockIdx.x / chunks / nplane;  // replica-major image index, 0 .. 3*nimg
+    plane = first_plane + pl;
+    first = chunk * kPosPerWg;
+    tc = psum - plane;
+  }
   const int lo = g.plane_start[plane];
   const int cnt = g.plane_start[plane + 1] - lo;
-  const int first = chunk * kPosPerWg;
   if (first >= cnt) return;  // uniform for the workgroup
-  const int tc = psum - plane;
   const int set = pn / g.nimg;
   const int group_in = CIN / g.ngroup;
   const int lane = threadIdx.x & (kWave - 1);
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(kConvBlock, EE_WAVES_PER_EU) void ee_conv_kernel(
   const int hw = g.order[lo + (active ? pi : first)];
   {
     const float *wrow = wp + ((size_t)set * cout + tc * GO) * RED;
-    for (int i = threadIdx.x; i < GO * RED; i += kConvBlock) wl[i] = wrow[i];
+    for (int i = threadIdx.x; i < GO * RED; i += BLOCK) wl[i] = wrow[i];
   }
   const Pos p = decode_pos(hw, g.h, g.w);
   const int h = g.h, w = g.w;
@@ -254,7 +267,48 @@ __global__ void ee_tables_kernel(EeGeom g, const float *__restrict__ y, const fl
     labels[r] = (int32_t)symbols[((((size_t)n * g.npart + p.tg) * g.ngroup + tc) * g.h + p.th) * g.w + p.tw];
 }
 
+// all symbols at once, rows in stream order [step][img][position in the step's window]
+__global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, const float *__restrict__ symbols,
+                                      int32_t *__restrict__ table, int32_t *__restrict__ labels, int nstep,
+                                      float bias, float total, float beta, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int idx = (int)(i % g.npos);
+    const int tc = (int)((i / g.npos) % g.ngroup);
+    const int n = (int)(i / g.npos / g.ngroup);
+    const int plane = g.pos_plane[idx];
+    const int s = plane + tc;
+    const int rows = g.h * g.npart;
+    const int st = s - g.ngroup + 1 < 0 ? 0 : s - g.ngroup + 1;
+    const int end = s < rows + g.w - 2 ? s + 1 : rows + g.w - 1;
+    const int len = g.plane_start[end] - g.plane_start[st];
+    const size_t r = (size_t)g.step_row[s] + (size_t)n * len + (idx - g.plane_start[st]);
+    const Pos p = decode_pos(g.order[idx], g.h, g.w);
+    const int cout = g.ngroup * 3;
+    float par[3][3];
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {
+      const float *base =
+          y + ((((size_t)(rep * g.nimg + n) * g.npart + p.tg) * g.h + p.th) * g.w + p.tw) * cout + tc * 3;
+#pragma unroll
+      for (int k = 0; k < 3; k++) par[rep][k] = base[k];
+    }
+    gmm_prepare_row(par[0], par[1], 3, beta);
+    gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
+    labels[r] = (int32_t)symbols[((((size_t)n * g.npart + p.tg) * g.ngroup + tc) * g.h + p.th) * g.w + p.tw];
+  }
+}
+
 }  // namespace
+
+int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
+                   int nstep, float bias, float total, float beta, void *stream) {
+  const long long count = (long long)g->nimg * g->ngroup * g->npos;
+  hipLaunchKernelGGL(ee_tables_bulk_kernel, dim3(pconv_grid(count)), dim3(256), 0, as_stream(stream), *g, y_last,
+                     symbols, table, labels, nstep, bias, total, beta, count);
+  PCONV_LAUNCH_CHECK("ee_tables_bulk");
+  return PCONV_OK;
+}
 
 int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, void *stream) {
   const int total = nset * cout * cin * KK;
@@ -264,18 +318,17 @@ int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, v
   return PCONV_OK;
 }
 
-int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
-            const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
-            int first_plane, int nplane, int longest_plane, int psum, void *stream) {
+template <int BLOCK, bool BULK>
+static int ee_conv_launch(const EeGeom *g, const float *x, int shared_input, const float *packed_w,
+                          const float *bias, const float *slope, const float *residual, float *y, int cin, int cout,
+                          int constrain, int pad_out, int first_plane, int nplane, int chunks, int psum,
+                          long long grid, void *stream) {
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv: cout must be 3 per group");
-  if (nplane <= 0 || longest_plane <= 0) return PCONV_OK;
-  const int chunks = (longest_plane + kPosPerWg - 1) / kPosPerWg;
-  const long long grid = (long long)3 * g->nimg * nplane * chunks;
-  PCONV_REQUIRE(grid < (1LL << 31), "ee_conv: grid too large");
-#define EE_LAUNCH(CIN, ITER)                                                                                  \
-  hipLaunchKernelGGL((ee_conv_kernel<CIN, ITER>), dim3((unsigned)grid), dim3(kConvBlock), 0, as_stream(stream), \
-                     *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, pad_out,       \
-                     first_plane, nplane, chunks, psum)
+  PCONV_REQUIRE(grid > 0 && grid < (1LL << 31), "ee_conv: grid %lld out of range", grid);
+#define EE_LAUNCH(CIN, ITER)                                                                                   \
+  hipLaunchKernelGGL((ee_conv_kernel<CIN, ITER, BLOCK, BULK>), dim3((unsigned)grid), dim3(BLOCK), 0,            \
+                     as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
+                     pad_out, first_plane, nplane, chunks, psum)
   if (cin == 14) {
     EE_LAUNCH(14, 6);
   } else if (cin == 42) {
@@ -295,6 +348,25 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
 #undef EE_LAUNCH
   PCONV_LAUNCH_CHECK("ee_conv");
   return PCONV_OK;
+}
+
+int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
+            const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
+            int first_plane, int nplane, int longest_plane, int psum, void *stream) {
+  if (nplane <= 0 || longest_plane <= 0) return PCONV_OK;
+  constexpr int per_wg = kConvBlock / kWave;
+  const int chunks = (longest_plane + per_wg - 1) / per_wg;
+  return ee_conv_launch<kConvBlock, false>(g, x, shared_input, packed_w, bias, slope, residual, y, cin, cout,
+                                           constrain, pad_out, first_plane, nplane, chunks, psum,
+                                           (long long)3 * g->nimg * nplane * chunks, stream);
+}
+
+int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
+                 const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
+                 void *stream) {
+  return ee_conv_launch<kBulkBlock, true>(g, x, shared_input, packed_w, bias, slope, residual, y, cin, cout,
+                                          constrain, pad_out, 0, 0, 0, 0,
+                                          (long long)3 * g->nimg * g->ngroup * g->nbulk_wg, stream);
 }
 
 int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,
