@@ -105,7 +105,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--frames-per-gpu", type=int, default=1)
+    ap.add_argument("--frames-per-gpu", type=int, default=4,
+                    help="frames each rank codes per step, in lock-step through the entropy wavefront")
+    ap.add_argument("--prime", type=int, default=2,
+                    help="untimed passes before the warm-up so that the caching allocator reaches steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="512x1024", help="HxW of the CPU baseline sample")
     args = ap.parse_args()
@@ -140,7 +143,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.prime + args.warmup):
         step()
     probe = ConvProbe()
     PCONV.conv_probe = probe
@@ -151,14 +154,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     PCONV.conv_probe = None
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    from pseudocylindrical_convolution_amd import sharding
+    totals, elapsed = sharding.reduce_metrics(
+        {"pixels": float(F * args.steps) * H * W, "bits": float(state["bits"]), "frames": float(F)}, elapsed, dev)
 
     per_kernel = probe.summarise()
-    total_pix = float(world * F * args.steps) * H * W
-    bits = state["bits"]
+    total_pix = totals["pixels"]
+    bits = totals["bits"] / world
     out = None
     if rank == 0:
         dom_key = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None

@@ -1,0 +1,166 @@
+"""Host-side geometry of the product (libpconv_hip.so host entry points, no GPU
+needed) against the oracle's restatement of the reference table kernels and
+against the golden outputs of the reference's own base.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pconv_cpu as O
+from pseudocylindrical_convolution_amd._native import call
+from pseudocylindrical_convolution_amd.PCONV_operator import set_weight
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W16 = np.array(set_weight(16, True), np.float32)
+
+
+def P(a):
+    return a.ctypes.data
+
+
+def widths(weight, npart, rows, width):
+    out = np.zeros(npart, np.int32)
+    call("pconv_host_tile_widths", P(np.asarray(weight, np.float32)), npart, rows, width, P(out))
+    return out
+
+
+def test_set_weight_matches_reference_golden():
+    d = np.load(os.path.join(GOLD, "set_weight.npz"))
+    for i, (n, opt, merge) in enumerate(d["args"]):
+        assert set_weight(int(n), bool(opt), bool(merge)) == d["out_%d" % i].tolist()
+    assert set_weight(16, True) == [15, 31, 54, 63, 63, 64, 64, 64, 64, 64, 64, 63, 63, 54, 31, 15]
+
+
+@pytest.mark.parametrize("width", [64, 128, 256, 512, 1024, 2048, 4096, 320, 100])
+def test_tile_widths(width):
+    for weight in (W16, np.array(set_weight(16, False), np.float32),
+                   np.array([0.3, 0.6, 0.8, 1, 1, 0.8, 0.6, 0.3], np.float32)):
+        n = len(weight)
+        got = widths(weight, n, 4 * n, width)
+        assert (got == O.widths_v3(weight, n, 4 * n, width)).all()
+        tidx = np.zeros(2 * n, np.int32)
+        O.lib().orc_cal_npart_hw_v2(O.I(4 * n), O.I(width), O.I(n), O._p(weight), O._p(tidx), None)
+        assert (got == tidx[n:]).all()
+    if width % 64 == 0:
+        assert widths(W16, 16, 64, width).tolist() == [int(v) * width // 64 for v in W16]
+
+
+@pytest.mark.parametrize("width", [64, 512, 1024, 4096, 300])
+def test_resampling_tap_tables(width):
+    wd = widths(W16, 16, 512, width)
+    col, coef = np.zeros(16 * width, np.int32), np.zeros(16 * width * 4, np.float32)
+    call("pconv_host_slice_taps", P(wd), 16, width, P(col), P(coef))
+    tidx = np.concatenate([np.arange(1, 17, dtype=np.int32) * 32, wd])
+    ref = np.zeros(16 * width * 5, np.float32)
+    O.lib().orc_slice_param(O.I(16), O.I(width), O._p(tidx), O._p(ref))
+    ref = ref.reshape(16 * width, 5)
+    assert (col == ref[:, 0].astype(np.int32)).all()
+    assert (coef.reshape(-1, 4) == ref[:, 1:]).all()          # bit-exact coefficients
+    call("pconv_host_uslice_taps", P(wd), 16, width, P(col), P(coef))
+    ref = np.zeros(16 * width * 5, np.float32)
+    O.lib().orc_uslice_param(O.I(16), O.I(width), O._p(wd), O._p(ref))
+    ref = ref.reshape(16 * width, 5)
+    assert (col == ref[:, 0].astype(np.int32)).all()
+    assert (coef.reshape(-1, 4) == ref[:, 1:]).all()
+    # cubic coefficients sum to one
+    assert np.abs(coef.reshape(-1, 4).sum(1) - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("h,w,pad", [(32, 1024, 1), (16, 512, 2), (2, 64, 2), (8, 256, 1), (64, 2048, 2)])
+def test_pad_halo_table(h, w, pad):
+    wd = widths(W16, 16, 16 * h, w)
+    n = 16 * 2 * pad
+    st, sr = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    col, wgt = np.zeros(n * w, np.int32), np.zeros(n * w, np.float32)
+    call("pconv_host_pad_table", P(wd), 16, h, w, pad, P(st), P(sr), P(col), P(wgt))
+    channel = 3
+    h2 = np.zeros(n, np.int32)
+    dst, src = np.zeros(n * w, np.int64), np.zeros(n * w, np.int64)
+    pcol, pt = np.zeros(n * w, np.int32), np.zeros(n * w, np.float32)
+    O.lib().orc_pseudo_context(O._p(wd), O._p(h2), O._p(dst), O._p(src), O._p(pcol), O._p(pt), O.I(channel), O.I(h),
+                               O.I(w), O.I(16), O.I(pad))
+    assert (st == h2).all()
+    for t in range(16):
+        for side in range(2):
+            for r in range(pad):
+                e = (t * 2 + side) * pad + r
+                v = int(wd[t])
+                assert (col[e * w:e * w + v] == pcol[e * w:e * w + v]).all()
+                assert (wgt[e * w:e * w + v] == pt[e * w:e * w + v]).all()
+                # the reference's source offset decodes to (tile, row) of the table
+                assert src[e * w] == (int(st[e]) * channel * h + int(sr[e])) * w
+    # poles mirror onto the same tile
+    assert st[0] == 0 and st[(15 * 2 + 1) * pad] == 15
+
+
+@pytest.mark.parametrize("h,w", [(4, 128), (2, 64), (16, 512), (1, 64)])
+def test_wavefront_schedule(h, w):
+    wd = widths(W16, 16, 16 * h, w)
+    rows = 16 * h
+    order, start = np.zeros(rows * w, np.int32), np.zeros(rows + w, np.int32)
+    call("pconv_host_wavefront", P(wd), 16, h, w, P(order), P(start))
+    o2, s2 = np.zeros(rows * w, np.int32), np.zeros(rows + w, np.int32)
+    O.lib().orc_wavefront(O._p(wd), O.I(16), O.I(h), O.I(w), O._p(o2), O._p(s2))
+    assert (order == o2).all() and (start == s2).all()
+    n = start[rows + w - 1]
+    assert n == h * int(wd.sum())
+    pos = order[:n]
+    assert len(set(pos.tolist())) == n                       # every valid position exactly once
+    plane = pos // w + pos % w
+    assert (np.diff(plane) >= 0).all()                        # sorted by plane
+    for p in (0, 5, rows + w - 2):
+        assert (plane[start[p]:start[p + 1]] == p).all()
+
+
+@pytest.mark.parametrize("h,w,channel", [(4, 128, 14), (2, 64, 42), (16, 512, 42)])
+def test_causal_halo_lists_equal_the_oracle_as_sets(h, w, channel):
+    pad = 2
+    wd = widths(W16, 16, 16 * h, w)
+    nplane = 16 * h + w + pad - 1
+    start = np.zeros(nplane + 1, np.int32)
+    n = call("pconv_host_causal_halo", P(wd), 16, channel, h, w, pad, None, None, None, None, None, P(start))
+    dst, s0, s1, pl = (np.zeros(n, np.int32) for _ in range(4))
+    wg = np.zeros(n, np.float32)
+    call("pconv_host_causal_halo", P(wd), 16, channel, h, w, pad, P(dst), P(s0), P(s1), P(wg), P(pl), P(start))
+    ctx = O.EntropyContextOp(16, 18, W16)
+    hidx, h2, odst, osrc, pcol, pt, lst, pad_idx = ctx.produce_param(channel, h, w, pad)
+    total = int(pad_idx[nplane])
+    assert total == n
+    lst = lst[:total * 3].reshape(total, 3)
+    mine = set()
+    for k in range(n):
+        mine.add((int(pl[k]), int(dst[k]), int(s0[k]), int(s1[k]), float(wg[k])))
+    theirs = set()
+    for a, b, plane in lst:
+        if b < 0:                                              # vertical halo: table index
+            idx = int(a)
+            tw = idx % w
+            qg = int(h2[idx // w])
+            c = int(pcol[idx])
+            d = int(odst[idx]) + tw + pad
+            src0 = -1 if c < 0 else int(osrc[idx]) + c + pad
+            src1 = int(osrc[idx]) + (c + 1) % int(hidx[qg]) + pad
+            theirs.add((int(plane), d, src0, src1, float(pt[idx])))
+        else:                                                  # wrap copy
+            theirs.add((int(plane), int(a), int(b), -2, 1.0))
+    assert mine == theirs
+    assert (start[:nplane + 1] == pad_idx[:nplane + 1]).all()
+    # the dense table used by the engine describes the same entries
+    col, wgt = np.zeros(16 * 2 * pad * w, np.int32), np.zeros(16 * 2 * pad * w, np.float32)
+    call("pconv_host_causal_table", P(wd), 16, h, w, pad, P(col), P(wgt))
+    nvert = sum(1 for e in theirs if e[3] != -2)
+    assert int((col != -2).sum()) == nvert
+
+
+def test_project_table_equals_oracle():
+    th = np.array([-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0], np.float32)
+    ph = np.array([0, 0, 0, 0, 0.25, 0.25, 0.25, 0.25, -0.25, -0.25, -0.25, -0.25, 0.5, -0.5], np.float32)
+    a = np.zeros(14 * 171 * 256 * 2, np.float32)
+    b = a.copy()
+    call("pconv_host_project_table", P(th), P(ph), 14, 0.5, 171, 256, 512, 1024, P(a))
+    O.lib().orc_projects_table(O._p(th), O._p(ph), O.I(14), O.F(0.5), O.I(171), O.I(256), O.I(512), O.I(1024), O._p(b))
+    assert (a == b).all()
+    xy = a.reshape(14, 171, 256, 2)
+    assert xy[..., 0].min() >= 0 and xy[..., 0].max() <= 1023 and xy[..., 1].min() >= 0 and xy[..., 1].max() <= 511
+    centre = xy[1, 85, 127:129].mean(0)                      # viewport (theta 0, phi 0) looks at the ERP centre
+    assert abs(centre[0] - 511.5) < 1.0 and abs(centre[1] - 255.5) < 1.0
