@@ -15,11 +15,6 @@ struct EeGeom {
   const int32_t *order, *plane_start;  // device, wavefront schedule
   const int32_t *vh_col;    // device, dense causal halo table
   const float *vh_wgt;
-  // per reduction index kk = tap*cin + ci, for cin = ngroup ([0]) and 3*ngroup ([1]):
-  //   tap_off  element offset of the tap from the window origin
-  //   tap_lim  (4 - kh - kw)*group_in - ci; the tap is causal iff tap_lim + (tc + slack)*group_in > 0
-  //   tap_pos  kh | kw << 4 | ci << 8 (for the halo path)
-  const int32_t *tap_off[2], *tap_lim[2], *tap_pos[2];
   // bulk (encoder) mode: every (plane, group) pair at once
   const int32_t *bulk_wg;    // device, (plane, first position) per workgroup of kBulkPos positions
   int nbulk_wg;
@@ -30,7 +25,9 @@ struct EeGeom {
 
 constexpr int kEeBulkPos = 8;  // positions per workgroup in bulk mode
 
-// weights (3, cout, cin, 5, 5) -> (3, cout, 25*cin) in reduction order tap*cin + ci
+// weights (3, cout, cin, 5, 5) -> per (set, output group) a slab [tap*cin + ci][4]
+// with the group's 3 rows interleaved (entropy_engine.hip)
+static inline size_t ee_packed_floats(int nset, int cout, int cin) { return (size_t)nset * (cout / 3) * cin * 25 * 4; }
 int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, void *stream);
 
 // one layer of one step.  x: cin channels, padded by 2; y: cout channels, padded

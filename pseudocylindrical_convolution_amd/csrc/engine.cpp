@@ -71,7 +71,6 @@ struct pconv_entropy_engine {
   EeGeom geom;
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
   float *vh_wgt = nullptr;
-  int32_t *tap_tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   int32_t *bulk_wg_d = nullptr, *pos_plane_d = nullptr, *step_row_d = nullptr;
   std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
@@ -131,26 +130,7 @@ struct pconv_entropy_engine {
       HIP_TRY(hipMemcpy(vh_col, col.data(), n * 4, hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(vh_wgt, wg.data(), n * 4, hipMemcpyHostToDevice));
     }
-    geom = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, {nullptr, nullptr},
-            {nullptr, nullptr}, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, 0};
-    for (int tt = 0; tt < 2; tt++) {  // tap tables for cin = G and cin = 3G
-      const int cin = tt == 0 ? ngroup : 3 * ngroup, group_in = cin / ngroup, red = cin * 25;
-      std::vector<int32_t> off(red), lim(red), pos(red);
-      for (int kk = 0; kk < red; kk++) {
-        const int ci = kk % cin, tap = kk / cin, kw = tap % 5, kh = tap / 5;
-        off[kk] = (kh * (w + 2 * kPad) + kw) * cin + ci;
-        lim[kk] = (4 - kh - kw) * group_in - ci;
-        pos[kk] = kh | (kw << 4) | (ci << 8);
-      }
-      const std::vector<int32_t> *src[3] = {&off, &lim, &pos};
-      for (int a = 0; a < 3; a++) {
-        HIP_TRY(hipMalloc(&tap_tab[tt][a], red * 4));
-        HIP_TRY(hipMemcpy(tap_tab[tt][a], src[a]->data(), red * 4, hipMemcpyHostToDevice));
-      }
-      geom.tap_off[tt] = tap_tab[tt][0];
-      geom.tap_lim[tt] = tap_tab[tt][1];
-      geom.tap_pos[tt] = tap_tab[tt][2];
-    }
+    geom = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, nullptr, 0, nullptr, nullptr, 0};
     {  // bulk (encoder) maps
       const int npos = sched_start[rows + w - 1];
       std::vector<int32_t> wg, pp(npos);
@@ -180,7 +160,7 @@ struct pconv_entropy_engine {
     HIP_TRY(hipMalloc(&ctx, ctx_elems() * 4));
     for (int l = 0; l < kLayers; l++) {
       HIP_TRY(hipMalloc(&act[l], act_elems(l) * 4));
-      HIP_TRY(hipMalloc(&lw[l], (size_t)3 * 3 * ngroup * layer_cin(l) * 25 * 4));
+      HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
     }
     HIP_TRY(hipMalloc(&packed, (size_t)nimg * max_len * 4));
     const size_t all_rows = sym_per_img * nimg;
@@ -201,8 +181,6 @@ struct pconv_entropy_engine {
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
     freed(ctx); freed(packed); freed(tables_d); freed(labels_d);
     freed(bulk_wg_d); freed(pos_plane_d); freed(step_row_d);
-    for (int tt = 0; tt < 2; tt++)
-      for (int a = 0; a < 3; a++) freed(tap_tab[tt][a]);
     for (int l = 0; l < kLayers; l++) {
       freed(act[l]);
       freed(lw[l]);
