@@ -26,6 +26,15 @@ constexpr uint64_t kSecond = kTop >> 1;
 
 inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
+// x / total, exact: the codec's tables always sum to 65536, so the two 64-bit
+// divisions per symbol of the textbook formulation become shifts
+struct Total {
+  uint32_t total;
+  int shift;  // >= 0 when total is a power of two
+  explicit Total(uint32_t t) : total(t), shift((t && !(t & (t - 1))) ? __builtin_ctz(t) : -1) {}
+  inline uint64_t div(uint64_t x) const { return shift >= 0 ? (x >> shift) : x / total; }
+};
+
 class BitSink {
  public:
   void clear() {
@@ -128,8 +137,9 @@ struct pconv_coder {
     if (sym_low == sym_high) return fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
     if (total > kMaxTotal)
       return fail(PCONV_CODER_ETOTAL, "Cannot code symbol because total is too large");
-    const uint64_t new_low = low + sym_low * range / total;
-    const uint64_t new_high = low + sym_high * range / total - 1;
+    const Total tot(total);
+    const uint64_t new_low = low + tot.div(sym_low * range);
+    const uint64_t new_high = low + tot.div(sym_high * range) - 1;
     low = new_low;
     high = new_high;
     // leading bits on which low and high agree leave the state
@@ -173,8 +183,9 @@ struct pconv_coder {
     if (total == 0) return fail(PCONV_CODER_EARG, "table total is zero");
     const uint64_t range = high - low + 1;
     const uint64_t offset = code - low;
+    const Total tot(total);
     const uint64_t value = ((offset + 1) * total - 1) / range;
-    if (value * range / total > offset) return fail(PCONV_CODER_EDESYNC, "Assertion error");
+    if (tot.div(value * range) > offset) return fail(PCONV_CODER_EDESYNC, "Assertion error");
     if (value >= total) return fail(PCONV_CODER_EDESYNC, "Assertion error");
     uint32_t start = 0, end = ncode;
     while (end - start > 1) {
@@ -186,7 +197,7 @@ struct pconv_coder {
     }
     if (start + 1 != end) return fail(PCONV_CODER_EDESYNC, "Assertion error");
     const uint32_t symbol = start;
-    if (offset < table[symbol] * range / total || table[symbol + 1] * range / total <= offset)
+    if (offset < tot.div(table[symbol] * range) || tot.div(table[symbol + 1] * range) <= offset)
       return fail(PCONV_CODER_EDESYNC, "Assertion error");
     int rc = narrow<false>(table, total, symbol);
     if (rc < 0) return rc;
