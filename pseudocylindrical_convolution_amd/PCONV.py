@@ -846,6 +846,17 @@ class EntropyGmmTableOp(_Op):
 # dense tile convolution (not a class of the reference's PCONV: it replaces the
 # cuDNN calls behind nn.Conv2d in model_zoo_v2.py)
 # ---------------------------------------------------------------------------
+def conv_col_limit(ctx_op, h, base, extra, like):
+    """(device int32[npart], npart): per latitude tile the first output column of a
+    tile convolution that nothing downstream can read -- valid width at tile width
+    `base` plus the `extra` halo columns the output still carries."""
+    key = ("limit", int(base), int(extra), like.device)
+    cache = ctx_op._cache
+    if key not in cache:
+        cache[key] = ctx_op._upload((ctx_op.widths_host(h, base) + int(extra)).astype(np.int32), like)
+    return cache[key], ctx_op.npart_
+
+
 def packed_conv_weight(owner, weight, stream):
     """[k][cout] fp32 slab of a conv weight for pconv_conv2d, cached on `owner`
     until the parameter is modified."""

@@ -84,6 +84,8 @@ _coder = None
 
 def _load(name):
     path = os.path.join(HERE, name)
+    if name == "libpconv_hip.so" and os.environ.get("PCONV_HIP_LIB"):
+        path = os.environ["PCONV_HIP_LIB"]  # kernel tuning experiments only
     if not os.path.exists(path):
         raise PconvError(
             "%s is not built: run `python -m pseudocylindrical_convolution_amd.build` "

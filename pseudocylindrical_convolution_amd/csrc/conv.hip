@@ -8,13 +8,18 @@
 // Orientation: couts are the MFMA "row" operand (A), pixels the "column" operand
 // (B), so an accumulator register holds 32 consecutive pixels of one output
 // channel and every store instruction writes two 128-byte row segments of the
-// NCHW output.  A workgroup (4 waves) owns BM couts x 128 pixels (2 output rows x
-// 64 columns).  Per chunk of KC input channels it stages the input patch and the
-// weight slab in LDS (double buffered; the next chunk's global loads are issued
-// before the MFMA block and written to LDS after it).  Each wave keeps MT x NT
-// 32x32 accumulators; per k-pair it reads MT + NT operands from LDS
-// (conflict-free: 32 consecutive couts / pixels per lane group) for MT*NT MFMAs
-// of 64 cycles each, so the matrix pipe is the only busy resource.
+// NCHW output.  A workgroup (WM x WN waves) owns BM couts x ROWS output rows x 64
+// columns.  Per chunk of KC input channels the input patch and the weight slab
+// go to LDS by LDS-DMA (global_load_lds, double buffered: the next chunk's DMA is
+// issued before the MFMA block and has all of it to land).  Each wave keeps
+// MT x NT 32x32 accumulators; per k-pair it reads MT + NT operands from LDS
+// (conflict-free: 32 consecutive couts / pixels per lane group), one k-pair
+// ahead of the MT*NT MFMAs of 64 cycles each that consume them.
+//
+// Measured (MI355X, 192->192 3x3, 16 x 64 x 2048 px): 127 TFLOP/s executed = 81 %
+// of the 157.3 TFLOP/s fp32-MFMA peak; the same loop without staging runs 141,
+// without staging and LDS reads 146.  Dead latitude columns are skipped on top
+// (col_limit): -16 % time at half resolution.
 //
 // Numerics contract: every output is ONE k-ascending fmaf chain starting at 0
 // (the MFMA accumulates k0 then k1 into the same register, chunks continue the
@@ -25,53 +30,62 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kThreads = 256;
-constexpr int kTileRows = 2;
 constexpr int kTileCols = 64;
 
-template <int KS, int S>
+template <int ROWS, int KS, int S>
 struct Patch {
   // sampling step of the staged patch (a strided 1x1 only needs every S-th pixel)
   static constexpr int PS = (KS == 1) ? S : 1;
   static constexpr int Q = S / PS;  // LDS step between neighbouring output pixels
-  static constexpr int PR = (kTileRows - 1) * Q + KS;
+  static constexpr int PR = (ROWS - 1) * Q + KS;
   static constexpr int PC = (kTileCols - 1) * Q + KS;
 };
 
+// WM x WN waves; a wave owns MT x NT accumulators of 32 couts x 32 pixels.  The
+// workgroup's pixel tile is WN*NT segments of 32 columns = ROWS rows x 64 columns.
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
 struct ConvCfg {
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int ROWS = WN * NT / 2;
   static constexpr int BM = 32 * MT * WM;
   static constexpr int KK = KC * KS * KS;  // reduction entries per chunk (even)
-  using P = Patch<KS, S>;
+  using P = Patch<ROWS, KS, S>;
   static constexpr int XSZ = KC * P::PR * P::PC;
   static constexpr int WSZ = KK * BM;
   static constexpr int STAGE = XSZ + WSZ;
-  static constexpr int XLD = (XSZ + kThreads - 1) / kThreads;        // floats / thread
-  static constexpr int WLD = (WSZ / 4 + kThreads - 1) / kThreads;    // float4 / thread
-  static_assert(WN * NT == 4, "pixel tile is 4 segments of 32");
+  static constexpr int XLD = (XSZ + THREADS - 1) / THREADS;        // floats / thread
+  static constexpr int WLD = (WSZ / 4 + THREADS - 1) / THREADS;    // float4 / thread
+  static_assert((WN * NT) % 2 == 0, "pixel tile is whole rows of two 32-column segments");
   static_assert(KK % 2 == 0, "chunk reduction length must be even");
   static_assert(BM % 4 == 0, "weight slab rows are float4 multiples");
 };
 
 // act: 0 none, 1 PReLU(slope per cout)
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
-__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
     const float *__restrict__ slope, float *__restrict__ out, int cin, int h, int w, int cout,
     int cout_pad, int ho, int wo, int act, int tiles_r, int tiles_c, int cblocks,
     const int32_t *__restrict__ col_limit, int npart) {
   using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
   using P = typename C::P;
+  constexpr int kThreads = C::THREADS;
+  constexpr int kTileRows = C::ROWS;
   extern __shared__ float lds[];
 
-  // block -> (cout block, column tile, row tile, tile-batch index)
+  // block -> (cout block, row tile, column tile, tile-batch index).  Row tiles run
+  // fastest on purpose: workgroups are dealt to the 8 XCDs x 4 shader engines by
+  // blockIdx % 32, and whether a workgroup is dead (col_limit) depends on its
+  // COLUMN tile only -- with columns fastest and 32 column tiles per row the dead
+  // ones all landed on the same engines and the live engines set the time
+  // (measured: 50 % dead workgroups, 0 % less time).
   int b = blockIdx.x;
   const int cb = b % cblocks;
   b /= cblocks;
-  const int tcx = b % tiles_c;
-  b /= tiles_c;
   const int trx = b % tiles_r;
-  const int t = b / tiles_r;
+  b /= tiles_r;
+  const int tcx = b % tiles_c;
+  const int t = b / tiles_c;
   const int r0 = trx * kTileRows, c0 = tcx * kTileCols;
   const int cout0 = cb * C::BM;
 
@@ -104,53 +118,67 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-  float xr[C::XLD];
-  float4 wr[C::WLD];
+  // Staging is LDS-DMA (global_load_lds): each wave instruction moves 64 x 4 B
+  // (patch) or 64 x 16 B (weight slab) from per-lane global addresses straight to
+  // a lane-linear LDS range -- no staging registers, no ds_write pass, and no
+  // address arithmetic in the chunk loop: the offsets are chunk-invariant up to a
+  // uniform base and computed once here.  (Register staging with in-loop address
+  // arithmetic cost 14 % of the kernel: the VALU shares its issue port with the
+  // MFMAs.)
+  unsigned xoffs[C::XLD], woffs[C::WLD];
+#pragma unroll
+  for (int j = 0; j < C::XLD; j++) {
+    int e = tid + j * kThreads;
+    e = e < C::XSZ ? e : 0;
+    const int pc = e % P::PC;
+    const int pr = (e / P::PC) % P::PR;
+    const int ci = e / (P::PC * P::PR);
+    int ir = r0 * S + pr * P::PS;
+    int ic = c0 * S + pc * P::PS;
+    ir = ir < h ? ir : h - 1;
+    ic = ic < w ? ic : w - 1;
+    xoffs[j] = (unsigned)((ci * h + ir) * w + ic);
+  }
+#pragma unroll
+  for (int j = 0; j < C::WLD; j++) {
+    int e4 = tid + j * kThreads;
+    e4 = e4 < C::WSZ / 4 ? e4 : 0;
+    const int kk = e4 / (C::BM / 4);
+    const int co = (e4 % (C::BM / 4)) * 4;
+    woffs[j] = (unsigned)(kk * cout_pad + co);
+  }
+  const int tail = cin % KC;  // channels of a ragged last chunk (0: none)
+  const size_t xstep = (size_t)KC * h * w, wstep = (size_t)C::KK * cout_pad;
 
-  auto load_chunk = [&](int chunk) {
-    const int ci0 = chunk * KC;
-#pragma unroll
-    for (int j = 0; j < C::XLD; j++) {
-      const int e = tid + j * kThreads;
-      float v = 0.f;
-      if (e < C::XSZ) {
-        const int pc = e % P::PC;
-        const int pr = (e / P::PC) % P::PR;
-        const int ci = e / (P::PC * P::PR);
-        int ir = r0 * S + pr * P::PS;
-        int ic = c0 * S + pc * P::PS;
-        ir = ir < h ? ir : h - 1;
-        ic = ic < w ? ic : w - 1;
-        if (ci0 + ci < cin) v = inp[((size_t)(ci0 + ci) * h + ir) * w + ic];
-      }
-      xr[j] = v;
-    }
-    const int k0 = ci0 * KS * KS;
-#pragma unroll
-    for (int j = 0; j < C::WLD; j++) {
-      const int e4 = tid + j * kThreads;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < C::WSZ / 4) {
-        const int kk = e4 / (C::BM / 4);
-        const int co = (e4 % (C::BM / 4)) * 4;
-        // rows past the real reduction length are zero in the packed weight
-        v = *reinterpret_cast<const float4 *>(wp + (size_t)(k0 + kk) * cout_pad + cout0 + co);
-      }
-      wr[j] = v;
-    }
-  };
-  auto store_chunk = [&](int buf) {
+  typedef __attribute__((address_space(3))) void lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void glb_ptr_t;
+  auto stage_chunk = [&](int chunk, int buf) {
     float *xs = lds + buf * C::STAGE;
     float *ws = xs + C::XSZ;
+    const float *xb = inp + chunk * xstep;
+    const bool ragged = tail != 0 && chunk == nchunk - 1;
 #pragma unroll
     for (int j = 0; j < C::XLD; j++) {
       const int e = tid + j * kThreads;
-      if (e < C::XSZ) xs[e] = xr[j];
+      if (e < C::XSZ) {
+        unsigned off = xoffs[j];
+        if (ragged) {
+          // channels past cin: read the last real one instead -- their rows of the
+          // packed weight are zero, so the product adds +0 to the chain
+          const int ci = e / (P::PC * P::PR);
+          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * h * w);
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(xs + j * kThreads + wave * 64),
+                                         4, 0, 0);
+      }
     }
+    const float *wb = wp + chunk * wstep + cout0;
 #pragma unroll
     for (int j = 0; j < C::WLD; j++) {
       const int e4 = tid + j * kThreads;
-      if (e4 < C::WSZ / 4) *reinterpret_cast<float4 *>(ws + e4 * 4) = wr[j];
+      if (e4 < C::WSZ / 4)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wb + woffs[j]),
+                                         (lds_ptr_t *)(ws + (j * kThreads + wave * 64) * 4), 16, 0, 0);
     }
   };
 
@@ -164,39 +192,51 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(
   }
   const int wbase = wm * MT * 32 + l31;
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+  stage_chunk(0, 0);
+  __syncthreads();  // (also waits for the DMA: vmcnt(0))
 
   for (int chunk = 0; chunk < nchunk; chunk++) {
     const int buf = chunk & 1;
-    if (chunk + 1 < nchunk) load_chunk(chunk + 1);
+    // the other buffer's last readers finished before the barrier that ended the
+    // previous iteration; the DMA has the whole MFMA block to land
+    if (chunk + 1 < nchunk) stage_chunk(chunk + 1, buf ^ 1);
     const float *xs = lds + buf * C::STAGE;
     const float *ws = xs + C::XSZ;
+    // operands of k-pair kp+1 are read from LDS before the MFMAs of k-pair kp are
+    // issued (two named register sets, the loop is unrolled in pairs), so the LDS
+    // latency hides behind 64*MT*NT cycles of matrix work instead of stalling the
+    // wave in front of every group
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+    // the two lane halves work on reduction entries 2kp and 2kp+1
+#define PCONV_READ_PAIR(KP, A, B)                                                            \
+  {                                                                                          \
+    constexpr int KS2 = KS * KS;                                                             \
+    const int ka = 2 * (KP), kb = 2 * (KP) + 1;                                              \
+    const int offa = (ka / KS2) * P::PR * P::PC + ((ka / KS) % KS) * P::PC + (ka % KS);      \
+    const int offb = (kb / KS2) * P::PR * P::PC + ((kb / KS) % KS) * P::PC + (kb % KS);      \
+    const int xoff = half ? offb : offa;                                                     \
+    const int woff = (2 * (KP) + half) * C::BM + wbase;                                      \
+    _Pragma("unroll") for (int m = 0; m < MT; m++) A[m] = ws[woff + m * 32];                 \
+    _Pragma("unroll") for (int n = 0; n < NT; n++) B[n] = xs[xbase[n] + xoff];               \
+  }
+#define PCONV_MFMA_BLOCK(A, B)                                                               \
+  {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    _Pragma("unroll") for (int m = 0; m < MT; m++) _Pragma("unroll") for (int n = 0; n < NT; n++) \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m], B[n], acc[m][n], 0, 0, 0);    \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  }
+    static_assert(C::KK % 4 == 0, "k-pairs are processed two at a time");
+    PCONV_READ_PAIR(0, a0, b0)
 #pragma unroll
-    for (int kp = 0; kp < C::KK / 2; kp++) {
-      // the two lane halves work on reduction entries 2kp and 2kp+1
-      constexpr int KS2 = KS * KS;
-      const int ka = 2 * kp, kb = 2 * kp + 1;
-      const int offa = (ka / KS2) * P::PR * P::PC + ((ka / KS) % KS) * P::PC + (ka % KS);
-      const int offb = (kb / KS2) * P::PR * P::PC + ((kb / KS) % KS) * P::PC + (kb % KS);
-      const int xoff = half ? offb : offa;
-      const int woff = (2 * kp + half) * C::BM + wbase;
-      float a[MT], bv[NT];
-#pragma unroll
-      for (int m = 0; m < MT; m++) a[m] = ws[woff + m * 32];
-#pragma unroll
-      for (int n = 0; n < NT; n++) bv[n] = xs[xbase[n] + xoff];
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+    for (int kq = 0; kq < C::KK / 4; kq++) {
+      PCONV_READ_PAIR(2 * kq + 1, a1, b1)
+      PCONV_MFMA_BLOCK(a0, b0)
+      if (2 * kq + 2 < C::KK / 2) PCONV_READ_PAIR(2 * kq + 2, a0, b0)
+      PCONV_MFMA_BLOCK(a1, b1)
     }
-    if (chunk + 1 < nchunk) {
-      store_chunk(buf ^ 1);  // other buffer: its last readers finished before the
-                             // barrier that ended the previous iteration
-    }
+#undef PCONV_READ_PAIR
+#undef PCONV_MFMA_BLOCK
     __syncthreads();
   }
 
@@ -238,6 +278,8 @@ int launch_conv(const float *in, const float *wp, const float *bias, const float
                 int tn, int cin, int h, int w, int cout, int cout_pad, int ho, int wo, int act,
                 const int32_t *col_limit, int npart, hipStream_t stream) {
   using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
+  constexpr int kThreads = C::THREADS;
+  constexpr int kTileRows = C::ROWS;
   const int tiles_r = (ho + kTileRows - 1) / kTileRows;
   const int tiles_c = (wo + kTileCols - 1) / kTileCols;
   const int cblocks = (cout + C::BM - 1) / C::BM;
@@ -305,11 +347,15 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
   hipStream_t s = as_stream(stream);
   int rc;
 #define ARGS in, packed_w, bias, slope, out, tn, cin, h, w, cout, cp, ho, wo, act, col_limit, npart, s
+  // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):
+  //   cout > 96 : 192 couts x (2 rows x 64 px), 4 waves of 96 x 64
+  //   cout > 32 :  96 couts x (4 rows x 64 px), 8 waves of 96 x 32
+  //   else      :  32 couts x (2 rows x 64 px), 4 waves of 32 x 32
 #define BY_TILE(KS, S, KC)                                         \
   if (cout > 96)                                                   \
     rc = launch_conv<3, 2, 2, 2, KS, S, KC>(ARGS);                 \
   else if (cout > 32)                                              \
-    rc = launch_conv<3, 1, 1, 4, KS, S, KC>(ARGS);                 \
+    rc = launch_conv<3, 1, 1, 8, KS, S, KC>(ARGS);                 \
   else                                                             \
     rc = launch_conv<1, 1, 1, 4, KS, S, KC>(ARGS);
   if (k == 3 && stride == 1) {

@@ -47,22 +47,33 @@ class ClipData(nn.Module):
 class TileConv2d(nn.Conv2d):
     """nn.Conv2d (no padding, k in {1,3}, stride in {1,2}) evaluated by the
     backend's tile convolution.  `fuse(x, prelu)` folds a following nn.PReLU into
-    the kernel epilogue.  PCONV_TILE_CONV=vendor routes to torch's own conv for
-    A/B timing on the GPU (never used for parity claims)."""
+    the kernel epilogue.  `live=(ctx, base)` tells the kernel which output columns
+    can ever be read: tile t only needs columns < widths_t(base) + (wo - base),
+    base = tile width of the scale the output lives in; 64-column blocks beyond
+    that are written as zeros without being computed (they are dead: every
+    consumer either trims them or never reads them).
+    PCONV_TILE_CONV=vendor routes to torch's own conv for A/B timing on the GPU
+    (never used for parity claims)."""
 
-    def _native(self, x, prelu):
+    def _native(self, x, prelu, live=None):
         ops = backend.ops()
         slope = prelu.weight if prelu is not None else None
         if os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d"):
             y = nn.functional.conv2d(x, self.weight, self.bias, self.stride)
             return nn.functional.prelu(y, slope) if slope is not None else y
-        return ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope)
+        limit, npart = None, 0
+        if live is not None and hasattr(ops, "conv_col_limit") and os.environ.get("PCONV_SKIP_DEAD", "1") == "1":
+            ctx, base = live
+            k, s = self.kernel_size[0], self.stride[0]
+            wo = (x.shape[3] - k) // s + 1
+            limit, npart = ops.conv_col_limit(ctx.native(x), x.shape[2], base, wo - base, x)
+        return ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope, limit, npart)
 
-    def forward(self, x):
-        return self._native(x, None)
+    def forward(self, x, live=None):
+        return self._native(x, None, live)
 
-    def fuse(self, x, prelu):
-        return self._native(x, prelu)
+    def fuse(self, x, prelu, live=None):
+        return self._native(x, prelu, live)
 
 
 def _conv(cin, cout, k, stride=1):
@@ -82,11 +93,13 @@ class ResidualBlock(nn.Module):
         self.relu2 = nn.PReLU(mid)
         self.conv3 = _conv(mid, channels, 1)
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx  # not a sub-module: the context is owned by the codec
 
     def forward(self, x):
-        y = self.conv1.fuse(self.pad(x), self.relu1)
-        y = self.conv2.fuse(y, self.relu2)
-        return self.trim(x + self.conv3(y))
+        live = (self.ctx, x.shape[3])
+        y = self.conv1.fuse(self.pad(x), self.relu1, live)
+        y = self.conv2.fuse(y, self.relu2, live)
+        return self.trim(x + self.conv3(y, live))
 
 
 class AttentionBlock(nn.Module):
@@ -98,9 +111,13 @@ class AttentionBlock(nn.Module):
         self.trunk = nn.Sequential(block(), block(), block())
         self.attention = nn.Sequential(block(), block(), block(), _conv(channels, channels, 1), nn.Sigmoid())
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.trim(x + self.trunk(x) * self.attention(x))
+        a = x
+        for i, m in enumerate(self.attention):
+            a = m(a, (self.ctx, x.shape[3])) if i == 3 else m(a)
+        return self.trim(x + self.trunk(x) * a)
 
 
 class ResidualBlockV2(nn.Module):
@@ -114,10 +131,12 @@ class ResidualBlockV2(nn.Module):
         self.conv2 = _conv(channels, channels, 3)
         self.relu2 = nn.PReLU(channels)
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        y = self.conv1.fuse(self.pad(x), self.relu1)
-        y = self.conv2.fuse(y, self.relu2)
+        live = (self.ctx, x.shape[3])
+        y = self.conv1.fuse(self.pad(x), self.relu1, live)
+        y = self.conv2.fuse(y, self.relu2, live)
         return self.trim(x + y)
 
 
@@ -134,11 +153,13 @@ class ResidualBlockDown(nn.Module):
         self.relu2 = PseudoGDNV2(channels, npart, ctx, device_id)
         self.short_cut = _conv(channel_in, channels, 1, 2)
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        t = self.short_cut(x)
-        y = self.conv1.fuse(self.pad1(x), self.relu1)
-        y = self.relu2(self.conv2(self.pad2(y)))
+        live = (self.ctx, x.shape[3] // 2)
+        t = self.short_cut(x, live)
+        y = self.conv1.fuse(self.pad1(x), self.relu1, live)
+        y = self.relu2(self.conv2(self.pad2(y), live))
         return self.trim(t + y)
 
 
@@ -150,9 +171,10 @@ class SphereConv2(nn.Module):
         self.conv = _conv(channel_in, channel_out, 3, 2)
         self.pad = PseudoPadV2(1, npart, ctx, device=device_id)
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.trim(self.conv(self.pad(x)))
+        return self.trim(self.conv(self.pad(x), (self.ctx, x.shape[3] // 2)))
 
 
 class EncoderV2(nn.Module):
@@ -170,9 +192,12 @@ class EncoderV2(nn.Module):
         )
         self.act = nn.Sigmoid()
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.trim(self.act(self.net(x)))
+        for i, m in enumerate(self.net):
+            x = m(x, (self.ctx, x.shape[3])) if i == len(self.net) - 1 else m(x)
+        return self.trim(self.act(x))
 
 
 class ResidualBlockUp(nn.Module):
@@ -190,11 +215,13 @@ class ResidualBlockUp(nn.Module):
         self.short_cut = _conv(channels, channels * 4, 1)
         self.dtow2 = Dtow(2, True, device_id)
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        br1 = self.dtow1(self.conv1.fuse(self.pad1(x), self.relu1))
-        br1 = self.relu2(self.conv2(self.pad2(br1)))
-        br2 = self.dtow2(self.short_cut(x))
+        w = x.shape[3]
+        br1 = self.dtow1(self.conv1.fuse(self.pad1(x), self.relu1, (self.ctx, w)))
+        br1 = self.relu2(self.conv2(self.pad2(br1), (self.ctx, 2 * w)))
+        br2 = self.dtow2(self.short_cut(x, (self.ctx, w)))
         return self.trim(br1 + br2)
 
 
@@ -205,9 +232,10 @@ class SphereConvOld(nn.Module):
         super(SphereConvOld, self).__init__()
         self.conv = _conv(channel_in, channel_out, 1)
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.trim(self.conv(x))
+        return self.trim(self.conv(x, (self.ctx, x.shape[3])))
 
 
 class DecoderV2(nn.Module):
@@ -225,6 +253,9 @@ class DecoderV2(nn.Module):
             _conv(channels, 12, 3),
             Dtow(2, True, device_id),
         )
+        self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.net(x)
+        for m in self.net:
+            x = m(x, (self.ctx, x.shape[3] - 2)) if isinstance(m, TileConv2d) else m(x)
+        return x
