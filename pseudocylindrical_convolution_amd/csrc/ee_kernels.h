@@ -5,6 +5,14 @@
 //   [image*npart + tile][row (+pad)][col (+pad)][C]
 // so that the 5 x 5 x C window of a position is 5 runs of 5*C contiguous floats.
 // The per-op API (include/pconv_hip.h) keeps the reference's NCHW.
+//
+// Halos are materialised by the PRODUCER of a value: whoever writes an interior
+// element also rewrites the halo entries that are interpolated from it (reverse
+// table rev_start / rev_entry) and, for the first two columns, their circular-wrap
+// copies.  A halo entry therefore always equals a*t + b*(1-t) of the current
+// values of its two source columns -- what a consumer evaluating
+// pconv_host_causal_table on the fly would read -- and every position's window is
+// a plain 5 x 5 x C block of the padded tile (no edge path in the consumers).
 #pragma once
 #include <stdint.h>
 
@@ -15,6 +23,9 @@ struct EeGeom {
   const int32_t *order, *plane_start;  // device, wavefront schedule
   const int32_t *vh_col;    // device, dense causal halo table
   const float *vh_wgt;
+  // device, CSR over (global row*w + col): halo entries (indices into vh_col) that
+  // read this interior column as one of their two sources
+  const int32_t *rev_start, *rev_entry;
   // bulk (encoder) mode: every (plane, group) pair at once
   const int32_t *bulk_wg;    // device, (plane, first position) per workgroup of kBulkPos positions
   int nbulk_wg;
@@ -44,6 +55,10 @@ int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float 
 // CDF rows and labels of all symbols, written in stream order
 int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
                    int nstep, float bias, float total, float beta, void *stream);
+
+// halos and wrap columns of a whole buffer of `nrep` images with C channels from
+// its interior (bulk mode, after a layer has been evaluated everywhere)
+int ee_halo_bulk(const EeGeom *g, float *buf, int C, int nrep, void *stream);
 
 // decoder: symbols of one step (packed [img][l]) + bias into ctx (nimg images)
 int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,

@@ -8,8 +8,8 @@
 //   * one host loop in C++, per step 1 scatter + 12 layer launches + 1 table
 //     launch (the per-op path: 12 halo updates, 12 convs, 5 adds, 2 extracts,
 //     4 GMM launches, driven from Python);
-//   * engine-private channels-last buffers and on-the-fly halos
-//     (entropy_engine.hip);
+//   * engine-private channels-last buffers whose halos are written by the
+//     producer of the value they derive from (entropy_engine.hip);
 //   * `nimg` frames advance in lock-step, one arithmetic coder each;
 //   * only the live rows of a step cross PCIe, through pinned buffers; the
 //     encoder never waits inside the loop: tables and labels of all steps are
@@ -70,6 +70,7 @@ struct pconv_entropy_engine {
   std::vector<int32_t> widths, sched_start;
   EeGeom geom;
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
+  int32_t *rev_start_d = nullptr, *rev_entry_d = nullptr;
   float *vh_wgt = nullptr;
   int32_t *bulk_wg_d = nullptr, *pos_plane_d = nullptr, *step_row_d = nullptr;
   std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
@@ -129,8 +130,40 @@ struct pconv_entropy_engine {
       HIP_TRY(hipMalloc(&vh_wgt, n * 4));
       HIP_TRY(hipMemcpy(vh_col, col.data(), n * 4, hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(vh_wgt, wg.data(), n * 4, hipMemcpyHostToDevice));
+      // reverse map: interior (global row, column) -> halo entries interpolated from it
+      // (entry en = ((tile*2 + side)*kPad + r)*w + column reads source columns c and
+      // c+1, circular, of the neighbouring tile's row; entry columns past the tile's
+      // valid width are never read and stay out)
+      std::vector<std::vector<int32_t>> lists((size_t)rows * w);
+      for (size_t en = 0; en < n; en++) {
+        const int cp = (int)(en % w);
+        size_t q = en / w;
+        const int r = (int)(q % kPad);
+        q /= kPad;
+        const int side = (int)(q & 1), tg = (int)(q >> 1);
+        const int c = col[en];
+        if (c == -2 || cp >= widths[tg]) continue;
+        const int srow = side ? (tg + 1) * h + r : tg * h - kPad + r;
+        if (srow < 0 || srow >= rows) continue;
+        const int wst = widths[srow / h];
+        int c1 = c + 1;
+        c1 = c1 >= wst ? c1 - wst : c1;
+        if (c >= 0) lists[(size_t)srow * w + c].push_back((int32_t)en);
+        if (c1 != c) lists[(size_t)srow * w + c1].push_back((int32_t)en);
+      }
+      std::vector<int32_t> rstart(lists.size() + 1, 0), rentry;
+      for (size_t k = 0; k < lists.size(); k++) {
+        rentry.insert(rentry.end(), lists[k].begin(), lists[k].end());
+        rstart[k + 1] = (int32_t)rentry.size();
+      }
+      if (rentry.empty()) rentry.push_back(0);
+      HIP_TRY(hipMalloc(&rev_start_d, rstart.size() * 4));
+      HIP_TRY(hipMalloc(&rev_entry_d, rentry.size() * 4));
+      HIP_TRY(hipMemcpy(rev_start_d, rstart.data(), rstart.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(rev_entry_d, rentry.data(), rentry.size() * 4, hipMemcpyHostToDevice));
     }
-    geom = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, nullptr, 0, nullptr, nullptr, 0};
+    geom = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, rev_start_d, rev_entry_d,
+            nullptr, 0, nullptr, nullptr, 0};
     {  // bulk (encoder) maps
       const int npos = sched_start[rows + w - 1];
       std::vector<int32_t> wg, pp(npos);
@@ -180,7 +213,7 @@ struct pconv_entropy_engine {
     };
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
     freed(ctx); freed(packed); freed(tables_d); freed(labels_d);
-    freed(bulk_wg_d); freed(pos_plane_d); freed(step_row_d);
+    freed(bulk_wg_d); freed(pos_plane_d); freed(step_row_d); freed(rev_start_d); freed(rev_entry_d);
     for (int l = 0; l < kLayers; l++) {
       freed(act[l]);
       freed(lw[l]);
@@ -220,6 +253,7 @@ struct pconv_entropy_engine {
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? act[l - 2] : nullptr;
       PC_TRY(ee_conv_bulk(&geom, in, l == 0, lw[l], lb[l], la[l], res, act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
                           l == kLayers - 1 ? 0 : kPad, st));
+      if (l != kLayers - 1) PC_TRY(ee_halo_bulk(&geom, act[l], hid, 3 * nimg, st));
     }
     return PCONV_OK;
   }
@@ -277,6 +311,7 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
   // step from seeing more than DInput2 would have given it
   PC_TRY(e->clear(st));
   PC_TRY(ee_fill_ctx(&e->geom, symbols, e->ctx, -e->bias, st));
+  PC_TRY(ee_halo_bulk(&e->geom, e->ctx, e->ngroup, e->nimg, st));
   const std::vector<int32_t> &step_row = e->step_row;  // rows are laid out [step][img][l]
   const size_t row = step_row[e->nsteps];
   if (e->stepwise_encoder) {

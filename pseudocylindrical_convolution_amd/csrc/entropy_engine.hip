@@ -7,10 +7,11 @@
 // lines instead of ~13 with NCHW (the per-op layout), where this step kernel is
 // bound by the number of cache lines the texture path has to look up.
 //
-// Halo taps are never stored: they are evaluated from the neighbouring tile's
-// interior with the causal rule of pconv_host_causal_table (what
-// EntropyCtxPadRun2 stores in the per-op path), which removes one launch per
-// layer per step.
+// Halos are written by the producer of the interior value they derive from (see
+// ee_kernels.h): the causal rule of pconv_host_causal_table (what
+// EntropyCtxPadRun2 stores in the per-op path, one launch per layer per step) is
+// applied in the epilogue of the kernel that computes the value, so consumers
+// read plain padded windows.
 #include "common.h"
 #include "ee_kernels.h"
 #include "gmm_device.h"
@@ -18,16 +19,11 @@
 namespace {
 
 constexpr int kWave = 64;
-#ifndef EE_CONV_BLOCK
-#define EE_CONV_BLOCK 256
-#endif
-#ifndef EE_POS_PER_WAVE
-#define EE_POS_PER_WAVE 2
-#endif
-#ifndef EE_WAVES_PER_EU
-#define EE_WAVES_PER_EU 4
-#endif
-constexpr int kConvBlock = EE_CONV_BLOCK;  // one wavefront position per wave
+constexpr int kConvBlock = 256;   // step kernel: 4 waves, one wavefront position per wave at a time
+constexpr int kPosPerWave = 4;    // positions a wave walks with its weights in registers
+// register cap of the step kernel: weights + offsets + window = 5 registers per tap
+// and lane, so wider layers get fewer, fatter waves
+constexpr int waves_per_eu(int iter) { return iter <= 20 ? 4 : (iter <= 40 ? 2 : 1); }
 constexpr int K = 5, KK = 25, HALF = 2, PAD = 2, GO = 3;
 
 struct Pos {
@@ -40,6 +36,29 @@ __device__ __forceinline__ Pos decode_pos(int hw, int h, int w) {
   p.tg = p.row / h;
   p.th = p.row - p.tg * h;
   return p;
+}
+
+// v[l] + v[l ^ off] for off = 32, 16, 8, 4, 2, 1 -- the canonical butterfly of the
+// masked convolution (every lane ends with the same total, bit for bit what
+// __shfl_xor gives: each step adds the same two numbers) -- on the cross-lane
+// VALU paths of gfx950 instead of six ds_bpermute round trips: half / row swaps,
+// a row rotate, one ds_swizzle (xor 4 has no DPP form) and two quad permutes.
+__device__ __forceinline__ float butterfly_sum(float v) {
+  {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));                      // xor 4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad [1,0,3,2]
+  return v;
 }
 
 // Packed weights: for every (set, output group) one slab [kk][4] holding the GO = 3
@@ -89,6 +108,79 @@ struct TapWalk {
   __device__ __forceinline__ int lim(int group_in) const { return (2 * HALF - kh - kw) * group_in - ci; }
 };
 
+// ---- halos ---------------------------------------------------------------
+
+// element index of padded (tile, row, col) inside one image of C channels
+__device__ __forceinline__ size_t tile_elem(int tile, int prow, int pcol, int h, int w, int C) {
+  return (((size_t)tile * (h + 2 * PAD) + prow) * (w + 2 * PAD) + pcol) * C;
+}
+
+// Rewrites halo entry `en` (index into the dense causal table: tile, side, halo
+// row, column) of channel ch from the current values of its two source columns;
+// SUBST: the caller has just produced the source at (own_row, own_col) and passes
+// its value in a register instead of re-reading its own store.
+template <bool SUBST>
+__device__ __forceinline__ void halo_write(const EeGeom &g, float *img, int C, int ch, int en, int own_row,
+                                           int own_col, float own_val) {
+  const int h = g.h, w = g.w;
+  const int cp = en % w;
+  int q = en / w;
+  const int r = q % PAD;
+  q /= PAD;
+  const int side = q & 1, tg = q >> 1;
+  const int c = g.vh_col[en];
+  if (c == -2) return;  // no causal source
+  const int srow = side ? (tg + 1) * h + r : tg * h - PAD + r;
+  if (srow < 0 || srow >= h * g.npart) return;
+  const int st = srow / h, sr = srow - st * h;
+  const int wst = g.widths[st];
+  int c1 = c + 1;
+  c1 = c1 >= wst ? c1 - wst : c1;
+  const float t = g.vh_wgt[en];
+  float a = 0.f, b;
+  if (c >= 0)
+    a = (SUBST && srow == own_row && c == own_col) ? own_val : img[tile_elem(st, sr + PAD, c + PAD, h, w, C) + ch];
+  b = (SUBST && srow == own_row && c1 == own_col) ? own_val : img[tile_elem(st, sr + PAD, c1 + PAD, h, w, C) + ch];
+  const float v = a * t + b * (1 - t);
+  const size_t dst = tile_elem(tg, side ? h + PAD + r : r, cp + PAD, h, w, C) + ch;
+  img[dst] = v;
+  if (cp < PAD) img[dst + (size_t)g.widths[tg] * C] = v;  // circular wrap of the first columns
+}
+
+// bulk: every halo entry and every wrap column of `nrep` images from the interior
+__global__ void ee_halo_bulk_kernel(EeGeom g, float *__restrict__ buf, int C, long long n_halo, long long n_wrap) {
+  const int h = g.h, w = g.w;
+  const size_t img_elems = (size_t)g.npart * (h + 2 * PAD) * (w + 2 * PAD) * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_halo + n_wrap;
+       i += (long long)gridDim.x * blockDim.x) {
+    if (i < n_halo) {
+      const int ch = (int)(i % C);
+      const long long q = i / C;
+      const int entries = g.npart * 2 * PAD * w;
+      const int en = (int)(q % entries);
+      const int rep = (int)(q / entries);
+      const int tg = en / w / PAD / 2;
+      if (en % w >= g.widths[tg]) continue;  // dead column: never read
+      halo_write<false>(g, buf + rep * img_elems, C, ch, en, -1, -1, 0.f);
+    } else {
+      const long long j = i - n_halo;
+      const int ch = (int)(j % C);
+      long long q = j / C;
+      const int k = (int)(q % PAD);
+      q /= PAD;
+      const int th = (int)(q % h);
+      q /= h;
+      const int tile = (int)(q % g.npart);
+      const int rep = (int)(q / g.npart);
+      float *img = buf + rep * img_elems;
+      const size_t src = tile_elem(tile, th + PAD, k + PAD, h, w, C) + ch;
+      img[src + (size_t)g.widths[tile] * C] = img[src];
+    }
+  }
+}
+
+// ---- layers --------------------------------------------------------------
+
 template <int CIN, int BLOCK>
 __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict__ wrow, int tid) {
   constexpr int N4 = slab_floats(CIN) / 4;
@@ -97,165 +189,153 @@ __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict
   for (int i = tid; i < N4; i += BLOCK) dst[i] = src[i];
 }
 
-// Step form: grid = 3 weight sets x planes of the step's window x `split`.  A
-// workgroup stages the weight rows of its (set, plane) pair ONCE (all positions
-// of a plane share the output group) and its waves then walk the plane's
-// (image, position) list with stride split*waves.  Measured on MI355X: staging
-// the 12.6 KB slab per 2 positions (one position per wave, small workgroups) made
-// the L2->LDS copy 64 % of the kernel time; amortising it over a whole list
-// slice removes that.
+// Step form: grid = 3 weight sets x planes of the step's window x `split`.  All
+// positions of a plane share the output group, so a wave loads its share of the
+// (set, group) weight slab ONCE into registers -- 17 taps x 3 rows per lane for 42
+// input channels, causally masked taps as zeros -- together with the window
+// offsets of those taps, and then walks the plane's (image, position) list with
+// stride split*waves: per position 17 gathers from one scalar base, 51 fmaf, the
+// butterfly, the epilogue.  No LDS, no barrier: the waves are independent.
 template <int CIN, int ITER, int BLOCK>
-__global__ __launch_bounds__(BLOCK, EE_WAVES_PER_EU) void ee_conv_kernel(
+__global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
     float *__restrict__ y, int cout, int constrain, int pad_out, int first_plane, int nplane, int split,
     int psum) {
   constexpr int RED = CIN * KK;
   constexpr int kWaves = BLOCK / kWave;
-  __shared__ __attribute__((aligned(16))) float wl[slab_floats(CIN)];
-  const int part = blockIdx.x % split;
-  const int pl = (blockIdx.x / split) % nplane;
-  const int set = blockIdx.x / split / nplane;
+  // block -> (set, plane, image, part); everything a wave does per position is
+  // wave-uniform, so it is kept in scalar registers (readfirstlane)
+  int b = blockIdx.x;
+  const int part = b % split;
+  b /= split;
+  const int img = b % g.nimg;
+  b /= g.nimg;
+  const int pl = b % nplane;
+  const int set = b / nplane;
   const int plane = first_plane + pl;
   const int lo = g.plane_start[plane];
   const int cnt = g.plane_start[plane + 1] - lo;
-  const int total = cnt * g.nimg;  // (image, position) pairs of this set and plane
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  if (part * kWaves >= total) return;  // uniform for the workgroup
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  if (part * kWaves + wave >= cnt) return;
   const int tc = psum - plane;
   const int group_in = CIN / g.ngroup;
-#ifndef EE_ABL_NOSTAGE
-  stage_weights<CIN, BLOCK>(wl, wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN), threadIdx.x);
-#endif
   const int h = g.h, w = g.w;
   const int win = w + 2 * PAD;
   const int tile_elems = (h + 2 * PAD) * win * CIN;
+  const size_t out_img = (size_t)g.npart * (h + 2 * pad_out) * (w + 2 * pad_out) * cout;
   const int slack = (constrain == 5) ? 0 : 1;
   // causality: input group gi at (qh, pw) is usable iff gi + qh + pw < psum
   // (constrain 5) or <= psum (constrain 6); qh + pw = row + tw - 4 + kh + kw, so
-  // the tap is usable iff ci < (tc + 4 - kh - kw + slack)*group_in.
+  // the tap is usable iff ci < (tc + 4 - kh - kw + slack)*group_in.  A masked tap
+  // gets zero weights: fmaf(x, 0, acc) leaves acc unchanged (x is finite).
   const int causal_base = (tc + slack) * group_in;
-  __syncthreads();  // weight rows are in LDS; the waves run independently from here
-#pragma unroll 1
-  for (int e = part * kWaves + wave; e < total; e += split * kWaves) {
-    const int img = e / cnt;
-    const Pos p = decode_pos(g.order[lo + e - img * cnt], h, w);
-    const int pn = set * g.nimg + img;  // replica-major image index
-    const int xi = shared_input ? img : pn;
-    const float *ximg = x + (size_t)xi * g.npart * tile_elems;
-    const int valid = g.widths[p.tg];
-    const bool edge = (p.th < HALF) || (p.th >= h - HALF) || (p.tw + HALF >= valid);
-    float xv[ITER];  // masked taps hold 0: fmaf(0, w, acc) leaves acc unchanged
-    // The tap walk depends on the lane only, but it is recomputed per position (a
-    // few VALU ops per tap): letting the compiler keep it in ~100 loop-invariant
-    // registers halves the occupancy and measured slower.
-    int lane_t = lane;
-    asm volatile("" : "+v"(lane_t));
-    TapWalk<CIN> tw(lane_t);
-    if (!edge) {
-      // window origin (th-2+PAD, tw-2+PAD) = (th, tw) in padded coordinates
-      const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
-#pragma unroll
-      for (int it = 0; it < ITER; it++) {
-        const int kk = lane_t + it * kWave;
-        const bool ok = (kk < RED) && (tw.lim(group_in) + causal_base > 0);
-        xv[it] = ok ? xin[tw.off(win)] : 0.f;
-        tw.next();
-      }
-    } else {
-      const int rows = h * g.npart;
-      int src_off[ITER], src_off1[ITER];  // element offsets inside the image, -1 = zero
-      float src_w[ITER];
-#pragma unroll
-      for (int it = 0; it < ITER; it++) {
-        const int kk = lane_t + it * kWave;
-        const int kh = tw.kh, kw = tw.kw, ci = tw.ci;
-        const bool ok = (kk < RED) && (tw.lim(group_in) + causal_base > 0);
-        tw.next();
-        src_off[it] = -1;
-        src_off1[it] = -1;
-        src_w[it] = 1.f;
-        if (ok) {
-          const int pr = p.th + kh;  // padded coordinates of the tap
-          int pc = p.tw + kw;
-          if (pc >= valid + PAD) pc -= valid;  // circular wrap of the first columns
-          if (pr >= PAD && pr < h + PAD) {
-            src_off[it] = p.tg * tile_elems + (pr * win + pc) * CIN + ci;  // left halo columns hold zeros
-          } else if (pc >= PAD) {
-            const int side = pr >= h + PAD;
-            const int r = side ? pr - (h + PAD) : pr;
-            const int row = side ? (p.tg + 1) * h + r : p.tg * h - PAD + r;
-            if (row >= 0 && row < rows) {
-              const int en = ((p.tg * 2 + side) * PAD + r) * w + pc - PAD;
-              const int c = g.vh_col[en];
-              if (c != -2) {
-                const int st = row / h;
-                const int rbase = st * tile_elems + ((row - st * h + PAD) * win + PAD) * CIN + ci;
-                const int wst = g.widths[st];
-                int c1 = c + 1;
-                c1 = c1 >= wst ? c1 - wst : c1;
-                src_w[it] = g.vh_wgt[en];
-                src_off[it] = (c < 0) ? -1 : rbase + c * CIN;
-                src_off1[it] = rbase + c1 * CIN;
-              }
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < ITER; it++) {
-        const float a = (src_off[it] >= 0) ? ximg[src_off[it]] : 0.f;
-        float v = a;
-        if (src_off1[it] >= 0) v = a * src_w[it] + ximg[src_off1[it]] * (1 - src_w[it]);
-        xv[it] = v;
-      }
-    }
-    float acc[GO];
-#pragma unroll
-    for (int o = 0; o < GO; o++) acc[o] = 0.f;
-    // the weight reads are loop-invariant; keep them as LDS reads (one 16-byte read
-    // per tap) instead of 51 hoisted registers: occupancy matters more
-    int lane_w = lane;
-    asm volatile("" : "+v"(lane_w));
+  const float4 *slab = reinterpret_cast<const float4 *>(wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN));
+  unsigned off[ITER];  // byte offsets: unsigned 32-bit, so the gathers are "scalar base + lane offset" loads
+  float w0[ITER], w1[ITER], w2[ITER];
+  {
+    TapWalk<CIN> tw(lane);
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
-      const int kk = lane_w + it * kWave;
-      const int kc = kk < RED ? kk : RED - 1;
-      const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);
-      acc[0] = fmaf(xv[it], wv.x, acc[0]);
-      acc[1] = fmaf(xv[it], wv.y, acc[1]);
-      acc[2] = fmaf(xv[it], wv.z, acc[2]);
+      const int kk = lane + it * kWave;
+      const bool ok = (kk < RED) && (tw.lim(group_in) + causal_base > 0);
+      off[it] = ok ? 4u * (unsigned)tw.off(win) : 0u;
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) wv = slab[kk];
+      w0[it] = wv.x;
+      w1[it] = wv.y;
+      w2[it] = wv.z;
+      tw.next();
     }
+  }
+  const int pout0 = tc * GO;
+  const int bidx = set * cout + pout0;
+  const float b0 = bias[bidx], b1 = bias[bidx + 1], b2 = bias[bidx + 2];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (slope) {
+    s0 = slope[bidx];
+    s1 = slope[bidx + 1];
+    s2 = slope[bidx + 2];
+  }
+  const int pn = set * g.nimg + img;  // replica-major image index
+  const int xi = shared_input ? img : pn;
+  const float *ximg = x + (size_t)xi * g.npart * tile_elems;
+  float *yimg = y + (size_t)pn * out_img;
+  const float *rimg = residual ? residual + (size_t)pn * out_img : nullptr;
+#pragma unroll 1
+  for (int e = part * kWaves + wave; e < cnt; e += split * kWaves) {
+    const Pos p = decode_pos(__builtin_amdgcn_readfirstlane(g.order[lo + e]), h, w);
+    // window origin (th-2+PAD, tw-2+PAD) = (th, tw) in padded coordinates
+    const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
+    const size_t oflat =
+        (((size_t)p.tg * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) + p.tw + pad_out) * cout + pout0;
+    float xv[ITER];
 #pragma unroll
-    for (int o = 0; o < GO; o++) {
-      float v = acc[o];
-      for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-      acc[o] = v;
+    for (int it = 0; it < ITER; it++) {
+      // (opaque to the optimiser: a zero-extension hoisted out of the loop would
+      // turn every gather into a 64-bit VALU add + a 2-register address)
+      unsigned o = off[it];
+      asm volatile("" : "+v"(o));
+      xv[it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
     }
-    if (lane < GO) {
-      float v = acc[0];
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;  // issued with the gathers: one memory round trip per position
+    if (rimg) {
+      r0 = rimg[oflat];
+      r1 = rimg[oflat + 1];
+      r2 = rimg[oflat + 2];
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int o = 1; o < GO; o++) v = (lane == o) ? acc[o] : v;
-      const int pout = tc * GO + lane;
-      const int bidx = set * cout + pout;
-      v = v + bias[bidx];
-      if (slope && v < 0) v = v * slope[bidx];
-      const size_t oidx = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
-                           p.tw + pad_out) * cout + pout;
-      if (residual) v = v + residual[oidx];
-      y[oidx] = v;
+    for (int it = 0; it < ITER; it++) {
+      a0 = fmaf(xv[it], w0[it], a0);
+      a1 = fmaf(xv[it], w1[it], a1);
+      a2 = fmaf(xv[it], w2[it], a2);
+    }
+    a0 = butterfly_sum(a0);
+    a1 = butterfly_sum(a1);
+    a2 = butterfly_sum(a2);
+    // every lane finishes all three outputs (the halo lanes below need them)
+    float v0 = a0 + b0, v1 = a1 + b1, v2 = a2 + b2;
+    if (slope) {
+      v0 = v0 < 0 ? v0 * s0 : v0;
+      v1 = v1 < 0 ? v1 * s1 : v1;
+      v2 = v2 < 0 ? v2 * s2 : v2;
+    }
+    if (rimg) {
+      v0 = v0 + r0;
+      v1 = v1 + r1;
+      v2 = v2 + r2;
+    }
+    const float mine = lane == 0 ? v0 : (lane == 1 ? v1 : v2);
+    if (lane < GO) yimg[oflat + lane] = mine;
+    if (pad_out) {
+      const int valid = g.widths[p.tg];
+      if (p.tw < PAD && lane < GO) yimg[oflat + (size_t)valid * cout + lane] = mine;  // circular wrap copy
+      if (p.th < PAD || p.th >= h - PAD) {
+        // this value feeds halo rows of the neighbouring tiles
+        const int grow = p.tg * h + p.th;
+        const int key = grow * w + p.tw;
+        const int r0 = g.rev_start[key], n = g.rev_start[key + 1] - r0;
+        for (int j0 = 0; j0 < n; j0 += kWave / GO) {
+          const int j = j0 + lane / GO, o = lane % GO;
+          if (lane < (kWave / GO) * GO && j < n)
+            halo_write<true>(g, yimg, cout, pout0 + o, g.rev_entry[r0 + j], grow, p.tw,
+                             o == 0 ? v0 : (o == 1 ? v1 : v2));
+        }
+      }
     }
   }
 }
 
 // Encoder ("bulk") form of the same layer: every symbol is known, so a position
 // can be evaluated for ALL its channel groups at once.  One wave per position
-// gathers the 5 x 5 x CIN window a single time (halo taps resolved once), then
-// walks the groups: the workgroup stages the group's weight rows in LDS and every
-// wave runs the masked fmaf chain + butterfly for that group.  Per output the
-// operations and their order are exactly those of the step kernel above
-// (psum = plane + group), so encoder and decoder tables agree bit for bit.
+// gathers the 5 x 5 x CIN window a single time, then walks the groups: the
+// workgroup stages the group's weight rows in LDS and every wave runs the masked
+// fmaf chain + butterfly for that group.  Per output the operations and their
+// order are exactly those of the step kernel above (psum = plane + group), so
+// encoder and decoder tables agree bit for bit.  Halos of the output are filled
+// afterwards by ee_halo_bulk.
 template <int CIN, int ITER, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
@@ -278,15 +358,12 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   const int win = w + 2 * PAD;
   const int tile_elems = (h + 2 * PAD) * win * CIN;
   const int xi = shared_input ? pn % g.nimg : pn;
-  const float *ximg = x + (size_t)xi * g.npart * tile_elems;
   const int slack = (constrain == 5) ? 0 : 1;
-  const int valid = g.widths[p.tg];
-  const bool edge = (p.th < HALF) || (p.th >= h - HALF) || (p.tw + HALF >= valid);
   float xv[ITER];
   int lim[ITER];  // causal limit of the tap; very negative for lanes past the reduction length
-  TapWalk<CIN> tw(lane);
-  if (!edge) {
-    const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
+  {
+    TapWalk<CIN> tw(lane);
+    const float *xin = x + ((size_t)xi * g.npart + p.tg) * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
       const int kk = lane + it * kWave;
@@ -294,44 +371,6 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
       lim[it] = in ? tw.lim(group_in) : -(1 << 30);
       xv[it] = in ? xin[tw.off(win)] : 0.f;
       tw.next();
-    }
-  } else {
-    const int rows = h * g.npart;
-#pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      const int kk = lane + it * kWave;
-      const int kh = tw.kh, kw = tw.kw, ci = tw.ci;
-      const bool in = active && kk < RED;
-      lim[it] = in ? tw.lim(group_in) : -(1 << 30);
-      tw.next();
-      float v = 0.f;
-      if (in) {
-        const int pr = p.th + kh;  // padded coordinates of the tap
-        int pc = p.tw + kw;
-        if (pc >= valid + PAD) pc -= valid;  // circular wrap of the first columns
-        if (pr >= PAD && pr < h + PAD) {
-          v = ximg[p.tg * tile_elems + (pr * win + pc) * CIN + ci];  // left halo columns hold zeros
-        } else if (pc >= PAD) {
-          const int side = pr >= h + PAD;
-          const int r = side ? pr - (h + PAD) : pr;
-          const int row = side ? (p.tg + 1) * h + r : p.tg * h - PAD + r;
-          if (row >= 0 && row < rows) {
-            const int e = ((p.tg * 2 + side) * PAD + r) * w + pc - PAD;
-            const int c = g.vh_col[e];
-            if (c != -2) {
-              const int st = row / h;
-              const int rbase = st * tile_elems + ((row - st * h + PAD) * win + PAD) * CIN + ci;
-              const int wst = g.widths[st];
-              int c1 = c + 1;
-              c1 = c1 >= wst ? c1 - wst : c1;
-              const float t = g.vh_wgt[e];
-              const float a = (c < 0) ? 0.f : ximg[rbase + c * CIN];
-              v = a * t + ximg[rbase + c1 * CIN] * (1 - t);
-            }
-          }
-        }
-      }
-      xv[it] = v;
     }
   }
   const size_t obase = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
@@ -374,15 +413,25 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   }
 }
 
+// decoder: one thread per (image, position) of the step that was just decoded
 __global__ void ee_scatter_kernel(EeGeom g, const float *__restrict__ packed, float *__restrict__ ctx, int lo,
                                   int len, int psum, float bias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= len * g.nimg) return;
   const int l = i % len, n = i / len;
-  const Pos p = decode_pos(g.order[lo + l], g.h, g.w);
+  const int h = g.h, w = g.w, C = g.ngroup;
+  const Pos p = decode_pos(g.order[lo + l], h, w);
   const int tc = psum - p.tw - p.row;
-  ctx[((((size_t)n * g.npart + p.tg) * (g.h + 2 * PAD) + p.th + PAD) * (g.w + 2 * PAD) + p.tw + PAD) * g.ngroup + tc] =
-      packed[i] + bias;
+  float *img = ctx + (size_t)n * g.npart * (h + 2 * PAD) * (w + 2 * PAD) * C;
+  const float v = packed[i] + bias;
+  const size_t dst = tile_elem(p.tg, p.th + PAD, p.tw + PAD, h, w, C) + tc;
+  img[dst] = v;
+  if (p.tw < PAD) img[dst + (size_t)g.widths[p.tg] * C] = v;
+  if (p.th < PAD || p.th >= h - PAD) {
+    const int key = p.row * w + p.tw;
+    const int r0 = g.rev_start[key], r1 = g.rev_start[key + 1];
+    for (int j = r0; j < r1; j++) halo_write<true>(g, img, C, tc, g.rev_entry[j], p.row, p.tw, v);
+  }
 }
 
 // one thread per NCHW element of the symbol tensor
@@ -494,12 +543,11 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   if (nplane <= 0 || longest_plane <= 0) return PCONV_OK;
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv: cout must be 3 per group");
   constexpr int kWaves = kConvBlock / kWave;
-  // workgroups per (set, plane): enough to fill the chip, few enough that each
-  // staged weight slab serves several positions per wave
-  const int pairs = longest_plane * g->nimg;
-  int split = (pairs + kWaves * EE_POS_PER_WAVE - 1) / (kWaves * EE_POS_PER_WAVE);
+  // workgroups per (set, plane): enough to fill the chip, few enough that the
+  // weights a wave holds in registers serve several positions
+  int split = (longest_plane + kWaves * kPosPerWave - 1) / (kWaves * kPosPerWave);
   if (split < 1) split = 1;
-  const long long grid = (long long)3 * nplane * split;
+  const long long grid = (long long)3 * nplane * g->nimg * split;
 #define EE_LAUNCH(CIN, ITER)                                                                                  \
   hipLaunchKernelGGL((ee_conv_kernel<CIN, ITER, kConvBlock>), dim3((unsigned)grid), dim3(kConvBlock), 0,      \
                      as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
@@ -555,6 +603,15 @@ int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float 
   }
 #undef EE_BULK
   PCONV_LAUNCH_CHECK("ee_conv_bulk");
+  return PCONV_OK;
+}
+
+int ee_halo_bulk(const EeGeom *g, float *buf, int C, int nrep, void *stream) {
+  const long long n_halo = (long long)nrep * g->npart * 2 * PAD * g->w * C;
+  const long long n_wrap = (long long)nrep * g->npart * g->h * PAD * C;
+  hipLaunchKernelGGL(ee_halo_bulk_kernel, dim3(pconv_grid(n_halo + n_wrap)), dim3(256), 0, as_stream(stream), *g,
+                     buf, C, n_halo, n_wrap);
+  PCONV_LAUNCH_CHECK("ee_halo_bulk");
   return PCONV_OK;
 }
 
