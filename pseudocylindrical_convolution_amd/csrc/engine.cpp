@@ -10,14 +10,23 @@
 //     4 GMM launches, driven from Python);
 //   * engine-private channels-last buffers whose halos are written by the
 //     producer of the value they derive from (entropy_engine.hip);
-//   * `nimg` frames advance in lock-step, one arithmetic coder each;
+//   * the frames of a call advance in lock-step inside a GROUP, one arithmetic
+//     coder each, and a call with two or more frames runs two groups in
+//     ping-pong: each group has its own buffers and HIP stream, and while the
+//     host decodes the symbols of group A's step the GPU evaluates group B's
+//     (the decoder alternates a GPU phase and a CPU phase per step; one group
+//     alone leaves each processor idle during the other's phase);
 //   * only the live rows of a step cross PCIe, through pinned buffers; the
 //     encoder never waits inside the loop: tables and labels of all steps are
 //     written to one device buffer in stream order, copied once and coded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -49,6 +58,63 @@ struct Window {
   int lo, len, first, nplane;
 };
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
+// Persistent helpers for the per-step arithmetic decoding: job(i) runs for
+// i = 0 (caller) .. n-1 (workers).  A step's decoding takes tens of microseconds,
+// far less than creating and joining threads, so the workers spin on a
+// generation counter for the duration of one decode call.
+class StepPool {
+ public:
+  explicit StepPool(int n) : n_(n) {
+    for (int i = 1; i < n_; i++) workers_.emplace_back([this, i] { loop(i); });
+  }
+  ~StepPool() {
+    stop_.store(true, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_release);
+    for (std::thread &t : workers_) t.join();
+  }
+  void run(const std::function<void(int)> &job) {
+    if (n_ == 1) {
+      job(0);
+      return;
+    }
+    job_ = &job;
+    done_.store(0, std::memory_order_relaxed);
+    gen_.fetch_add(1, std::memory_order_release);
+    job(0);
+    while (done_.load(std::memory_order_acquire) < n_ - 1) cpu_relax();
+  }
+
+ private:
+  void loop(int i) {
+    int seen = 0;
+    for (;;) {
+      int spins = 0;
+      while (gen_.load(std::memory_order_acquire) == seen) {
+        cpu_relax();
+        if (++spins > 4096) {
+          std::this_thread::yield();
+          spins = 0;
+        }
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      if (stop_.load(std::memory_order_acquire)) return;
+      (*job_)(i);
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  int n_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)> *job_ = nullptr;
+  std::atomic<int> gen_{0}, done_{0};
+  std::atomic<bool> stop_{false};
+};
+
 template <typename Fn>
 void for_each_image(int nimg, Fn fn) {
   if (nimg == 1) {
@@ -61,6 +127,24 @@ void for_each_image(int nimg, Fn fn) {
   for (std::thread &t : pool) t.join();
 }
 
+// frames that advance in lock-step: buffers, stream and schedule offsets of their own
+struct Group {
+  int nimg = 0, first = 0;  // frames of the call: first .. first + nimg - 1
+  EeGeom geom;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
+  float *act[kLayers] = {nullptr};  // (3*nimg*npart, h+2p, w+2p, 3G), persistent across steps
+  float *packed = nullptr;          // decoder: symbols of the previous step [img][len]
+  int32_t *tables_d = nullptr, *labels_d = nullptr;
+  int32_t *tables_h = nullptr, *labels_h = nullptr;  // pinned
+  float *packed_h = nullptr;                         // pinned
+  int32_t *step_row_d = nullptr;
+  std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
+  std::vector<int32_t> sym;
+  StepPool *pool = nullptr;
+};
+
 }  // namespace
 
 struct pconv_entropy_engine {
@@ -68,30 +152,24 @@ struct pconv_entropy_engine {
   float bias, total, beta;
   int rows, nsteps, longest_plane = 0;
   std::vector<int32_t> widths, sched_start;
-  EeGeom geom;
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
   int32_t *rev_start_d = nullptr, *rev_entry_d = nullptr;
   float *vh_wgt = nullptr;
-  int32_t *bulk_wg_d = nullptr, *pos_plane_d = nullptr, *step_row_d = nullptr;
-  std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
+  int32_t *bulk_wg_d = nullptr, *pos_plane_d = nullptr;
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
   const float *lb[kLayers] = {nullptr}, *la[kLayers] = {nullptr};
   bool bound[kLayers] = {false};
-  float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
-  float *act[kLayers] = {nullptr};  // (3*nimg*npart, h+2p, w+2p, 3G), persistent across steps
-  float *packed = nullptr;          // decoder: symbols of the previous step [img][len]
-  int32_t *tables_d = nullptr, *labels_d = nullptr;
-  int32_t *tables_h = nullptr, *labels_h = nullptr;  // pinned
-  float *packed_h = nullptr;                         // pinned
+  std::vector<Group> groups;
+  hipEvent_t entry = nullptr;
   size_t sym_per_img = 0, max_len = 0;
   std::vector<std::vector<uint8_t>> streams;
   std::vector<pconv_coder *> coders;
 
-  size_t ctx_elems() const { return (size_t)nimg * npart * ngroup * (h + 2 * kPad) * (w + 2 * kPad); }
-  size_t act_elems(int l) const {
+  size_t ctx_elems(int n) const { return (size_t)n * npart * ngroup * (h + 2 * kPad) * (w + 2 * kPad); }
+  size_t act_elems(int l, int n) const {
     const int p = (l == kLayers - 1) ? 0 : kPad;
-    return (size_t)3 * nimg * npart * 3 * ngroup * (h + 2 * p) * (w + 2 * p);
+    return (size_t)3 * n * npart * 3 * ngroup * (h + 2 * p) * (w + 2 * p);
   }
   int layer_cin(int l) const { return l == 0 ? ngroup : 3 * ngroup; }
 
@@ -100,6 +178,30 @@ struct pconv_entropy_engine {
     int end = psum < rows + w - 2 ? psum + 1 : rows + w - 1;
     if (st >= end) return {0, 0, 0, 0};
     return {sched_start[st], sched_start[end] - sched_start[st], st, end - st};
+  }
+
+  int init_group(Group &g, int first, int n, const EeGeom &base) {
+    g.nimg = n;
+    g.first = first;
+    g.geom = base;
+    g.geom.nimg = n;
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    g.step_row.assign(nsteps + 1, 0);
+    for (int s = 0; s < nsteps; s++) g.step_row[s + 1] = g.step_row[s] + window(s).len * n;
+    HIP_TRY(hipMalloc(&g.step_row_d, g.step_row.size() * 4));
+    HIP_TRY(hipMemcpy(g.step_row_d, g.step_row.data(), g.step_row.size() * 4, hipMemcpyHostToDevice));
+    g.geom.step_row = g.step_row_d;
+    HIP_TRY(hipMalloc(&g.ctx, ctx_elems(n) * 4));
+    for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&g.act[l], act_elems(l, n) * 4));
+    HIP_TRY(hipMalloc(&g.packed, (size_t)n * max_len * 4));
+    const size_t all_rows = sym_per_img * n;
+    HIP_TRY(hipMalloc(&g.tables_d, all_rows * (nlevels + 1) * 4));
+    HIP_TRY(hipMalloc(&g.labels_d, all_rows * 4));
+    HIP_TRY(hipHostMalloc(&g.tables_h, all_rows * (nlevels + 1) * 4));
+    HIP_TRY(hipHostMalloc(&g.labels_h, all_rows * 4));
+    HIP_TRY(hipHostMalloc(&g.packed_h, (size_t)n * max_len * 4));
+    return PCONV_OK;
   }
 
   int init(const float *tile_weight) {
@@ -162,8 +264,8 @@ struct pconv_entropy_engine {
       HIP_TRY(hipMemcpy(rev_start_d, rstart.data(), rstart.size() * 4, hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(rev_entry_d, rentry.data(), rentry.size() * 4, hipMemcpyHostToDevice));
     }
-    geom = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, rev_start_d, rev_entry_d,
-            nullptr, 0, nullptr, nullptr, 0};
+    EeGeom base = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, rev_start_d,
+                   rev_entry_d, nullptr, 0, nullptr, nullptr, 0};
     {  // bulk (encoder) maps
       const int npos = sched_start[rows + w - 1];
       std::vector<int32_t> wg, pp(npos);
@@ -175,33 +277,25 @@ struct pconv_entropy_engine {
           wg.push_back(f);
         }
       }
-      step_row.assign(nsteps + 1, 0);
-      for (int s = 0; s < nsteps; s++) step_row[s + 1] = step_row[s] + window(s).len * nimg;
       HIP_TRY(hipMalloc(&bulk_wg_d, wg.size() * 4));
       HIP_TRY(hipMemcpy(bulk_wg_d, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&pos_plane_d, pp.size() * 4));
       HIP_TRY(hipMemcpy(pos_plane_d, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc(&step_row_d, step_row.size() * 4));
-      HIP_TRY(hipMemcpy(step_row_d, step_row.data(), step_row.size() * 4, hipMemcpyHostToDevice));
-      geom.bulk_wg = bulk_wg_d;
-      geom.nbulk_wg = (int)(wg.size() / 2);
-      geom.pos_plane = pos_plane_d;
-      geom.step_row = step_row_d;
-      geom.npos = npos;
+      base.bulk_wg = bulk_wg_d;
+      base.nbulk_wg = (int)(wg.size() / 2);
+      base.pos_plane = pos_plane_d;
+      base.npos = npos;
       stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
     }
-    HIP_TRY(hipMalloc(&ctx, ctx_elems() * 4));
-    for (int l = 0; l < kLayers; l++) {
-      HIP_TRY(hipMalloc(&act[l], act_elems(l) * 4));
-      HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
-    }
-    HIP_TRY(hipMalloc(&packed, (size_t)nimg * max_len * 4));
-    const size_t all_rows = sym_per_img * nimg;
-    HIP_TRY(hipMalloc(&tables_d, all_rows * (nlevels + 1) * 4));
-    HIP_TRY(hipMalloc(&labels_d, all_rows * 4));
-    HIP_TRY(hipHostMalloc(&tables_h, all_rows * (nlevels + 1) * 4));
-    HIP_TRY(hipHostMalloc(&labels_h, all_rows * 4));
-    HIP_TRY(hipHostMalloc(&packed_h, (size_t)nimg * max_len * 4));
+    for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
+    // two groups in ping-pong when there are frames for both (PCONV_ENGINE_GROUPS=1: A/B timing)
+    int ngroups = nimg >= 2 ? 2 : 1;
+    if (const char *env = getenv("PCONV_ENGINE_GROUPS")) ngroups = (atoi(env) >= 2 && nimg >= 2) ? 2 : 1;
+    groups.resize(ngroups);
+    const int na = (nimg + ngroups - 1) / ngroups;
+    PC_TRY(init_group(groups[0], 0, na, base));
+    if (ngroups == 2) PC_TRY(init_group(groups[1], na, nimg - na, base));
+    HIP_TRY(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
     streams.resize(nimg);
     for (int i = 0; i < nimg; i++) coders.push_back(pconv_coder_new(nullptr));
     return PCONV_OK;
@@ -212,49 +306,140 @@ struct pconv_entropy_engine {
       if (p) (void)hipFree(p);
     };
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
-    freed(ctx); freed(packed); freed(tables_d); freed(labels_d);
-    freed(bulk_wg_d); freed(pos_plane_d); freed(step_row_d); freed(rev_start_d); freed(rev_entry_d);
-    for (int l = 0; l < kLayers; l++) {
-      freed(act[l]);
-      freed(lw[l]);
+    freed(bulk_wg_d); freed(pos_plane_d); freed(rev_start_d); freed(rev_entry_d);
+    for (int l = 0; l < kLayers; l++) freed(lw[l]);
+    for (Group &g : groups) {
+      freed(g.ctx); freed(g.packed); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
+      for (int l = 0; l < kLayers; l++) freed(g.act[l]);
+      if (g.tables_h) (void)hipHostFree(g.tables_h);
+      if (g.labels_h) (void)hipHostFree(g.labels_h);
+      if (g.packed_h) (void)hipHostFree(g.packed_h);
+      if (g.done) (void)hipEventDestroy(g.done);
+      if (g.stream) (void)hipStreamDestroy(g.stream);
     }
-    if (tables_h) (void)hipHostFree(tables_h);
-    if (labels_h) (void)hipHostFree(labels_h);
-    if (packed_h) (void)hipHostFree(packed_h);
+    if (entry) (void)hipEventDestroy(entry);
     for (pconv_coder *c : coders) pconv_coder_free(c);
   }
 
-  int clear(hipStream_t st) {
-    HIP_TRY(hipMemsetAsync(ctx, 0, ctx_elems() * 4, st));
-    for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(act[l], 0, act_elems(l) * 4, st));
+  // group streams start after everything the caller has queued (weights, symbols)
+  int fork(hipStream_t caller) {
+    HIP_TRY(hipEventRecord(entry, caller));
+    for (Group &g : groups) HIP_TRY(hipStreamWaitEvent(g.stream, entry, 0));
+    return PCONV_OK;
+  }
+  // ... and the caller's stream continues after the groups
+  int join(hipStream_t caller) {
+    for (Group &g : groups) {
+      HIP_TRY(hipEventRecord(g.done, g.stream));
+      HIP_TRY(hipStreamWaitEvent(caller, g.done, 0));
+    }
+    return PCONV_OK;
+  }
+
+  int clear(Group &g) {
+    HIP_TRY(hipMemsetAsync(g.ctx, 0, ctx_elems(g.nimg) * 4, g.stream));
+    for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(g.act[l], 0, act_elems(l, g.nimg) * 4, g.stream));
     return PCONV_OK;
   }
 
   // the 12 layers of one wavefront step (EntropyConvDBT / EntropyResidualBlockDBT
   // of pseudo_codec.py:27-51, 79-87)
-  int network_step(int s, const Window &cur, hipStream_t st) {
+  int network_step(Group &g, int s, const Window &cur) {
     if (cur.len <= 0) return PCONV_OK;
     const int hid = 3 * ngroup;
     for (int l = 0; l < kLayers; l++) {
-      const float *in = (l == 0) ? ctx : act[l - 1];
+      const float *in = (l == 0) ? g.ctx : g.act[l - 1];
       // second conv of a residual block: += block input, folded into the epilogue
-      const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? act[l - 2] : nullptr;
-      PC_TRY(ee_conv(&geom, in, l == 0, lw[l], lb[l], la[l], res, act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
-                     l == kLayers - 1 ? 0 : kPad, cur.first, cur.nplane, longest_plane, s, st));
+      const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
+      PC_TRY(ee_conv(&g.geom, in, l == 0, lw[l], lb[l], la[l], res, g.act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
+                     l == kLayers - 1 ? 0 : kPad, cur.first, cur.nplane, longest_plane, s, g.stream));
     }
     return PCONV_OK;
   }
 
   // every layer once over all (plane, group) pairs: the encoder knows all symbols
-  int network_bulk(hipStream_t st) {
+  int network_bulk(Group &g) {
     const int hid = 3 * ngroup;
     for (int l = 0; l < kLayers; l++) {
-      const float *in = (l == 0) ? ctx : act[l - 1];
-      const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? act[l - 2] : nullptr;
-      PC_TRY(ee_conv_bulk(&geom, in, l == 0, lw[l], lb[l], la[l], res, act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
-                          l == kLayers - 1 ? 0 : kPad, st));
-      if (l != kLayers - 1) PC_TRY(ee_halo_bulk(&geom, act[l], hid, 3 * nimg, st));
+      const float *in = (l == 0) ? g.ctx : g.act[l - 1];
+      const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
+      PC_TRY(ee_conv_bulk(&g.geom, in, l == 0, lw[l], lb[l], la[l], res, g.act[l], layer_cin(l), hid,
+                          l == 0 ? 5 : 6, l == kLayers - 1 ? 0 : kPad, g.stream));
+      if (l != kLayers - 1) PC_TRY(ee_halo_bulk(&g.geom, g.act[l], hid, 3 * g.nimg, g.stream));
     }
+    return PCONV_OK;
+  }
+
+  size_t image_symbols() const { return (size_t)npart * ngroup * h * w; }
+
+  // encoder, GPU part of one group: CDF rows and labels of all its symbols -> pinned host memory
+  int encode_tables(Group &g, const float *symbols) {
+    const int cols = nlevels + 1;
+    const float *sym = symbols + (size_t)g.first * image_symbols();
+    // all symbols are known: fill the context once; the causal masks keep every
+    // step from seeing more than DInput2 would have given it
+    PC_TRY(clear(g));
+    PC_TRY(ee_fill_ctx(&g.geom, sym, g.ctx, -bias, g.stream));
+    PC_TRY(ee_halo_bulk(&g.geom, g.ctx, ngroup, g.nimg, g.stream));
+    const size_t row = g.step_row[nsteps];
+    if (stepwise_encoder) {
+      for (int s = 0; s < nsteps; s++) {
+        const Window cur = window(s);
+        PC_TRY(network_step(g, s, cur));
+        PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], sym, g.tables_d + (size_t)g.step_row[s] * cols,
+                         g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, g.stream));
+      }
+    } else {
+      PC_TRY(network_bulk(g));
+      PC_TRY(ee_tables_bulk(&g.geom, g.act[kLayers - 1], sym, g.tables_d, g.labels_d, nlevels, bias, total, beta,
+                            g.stream));
+    }
+    HIP_TRY(hipMemcpyAsync(g.tables_h, g.tables_d, row * cols * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.labels_h, g.labels_d, row * 4, hipMemcpyDeviceToHost, g.stream));
+    return PCONV_OK;
+  }
+
+  // decoder, GPU phase of step s for one group (everything is queued, nothing waits)
+  int decode_enqueue(Group &g, int s, const Window &prev, const Window &cur) {
+    const int cols = nlevels + 1;
+    if (s > 0) PC_TRY(ee_scatter(&g.geom, g.packed, g.ctx, prev.lo, prev.len, s - 1, -bias, g.stream));
+    if (cur.len > 0) {
+      const size_t nrow = (size_t)cur.len * g.nimg;
+      PC_TRY(network_step(g, s, cur));
+      PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_d, nullptr, cur.lo, cur.len, s, nlevels, bias,
+                       total, beta, g.stream));
+      HIP_TRY(hipMemcpyAsync(g.tables_h, g.tables_d, nrow * cols * 4, hipMemcpyDeviceToHost, g.stream));
+    }
+    return PCONV_OK;
+  }
+
+  // decoder, CPU phase of step s for one group: wait for its tables, decode, send the symbols back
+  int decode_symbols(Group &g, int s, const Window &cur, double *t_wait, double *t_coder) {
+    if (cur.len <= 0) return PCONV_OK;
+    const int cols = nlevels + 1;
+    const size_t nrow = (size_t)cur.len * g.nimg;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    g.sym.resize(nrow);
+    std::atomic<int> status{0};
+    const std::function<void(int)> job = [&](int i) {
+      const int rc = pconv_coder_decodes_i32(coders[g.first + i], g.tables_h + (size_t)i * cur.len * cols, nlevels,
+                                             g.sym.data() + (size_t)i * cur.len, cur.len);
+      if (rc < 0) status.store(rc);
+      float *dst = g.packed_h + (size_t)i * cur.len;
+      const int32_t *src = g.sym.data() + (size_t)i * cur.len;
+      for (int k = 0; k < cur.len; k++) dst[k] = (float)src[k];
+    };
+    g.pool->run(job);
+    if (status.load() < 0) {
+      pconv_set_error("ee_decode: arithmetic decoder desynchronised at step %d", s);
+      return PCONV_EINVAL;
+    }
+    HIP_TRY(hipMemcpyAsync(g.packed, g.packed_h, nrow * 4, hipMemcpyHostToDevice, g.stream));
+    const auto t2 = std::chrono::steady_clock::now();
+    *t_wait += std::chrono::duration<double>(t1 - t0).count();
+    *t_coder += std::chrono::duration<double>(t2 - t1).count();
     return PCONV_OK;
   }
 };
@@ -305,50 +490,36 @@ int pconv_ee_steps(const pconv_entropy_engine *e) { return e ? e->nsteps : -1; }
 int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream) {
   PCONV_REQUIRE(e && symbols, "ee_encode: bad argument");
   for (int l = 0; l < kLayers; l++) PCONV_REQUIRE(e->bound[l], "ee_encode: layer %d has no weights", l);
-  hipStream_t st = as_stream(stream);
+  hipStream_t caller = as_stream(stream);
   const int cols = e->nlevels + 1;
-  // all symbols are known: fill the context once; the causal masks keep every
-  // step from seeing more than DInput2 would have given it
-  PC_TRY(e->clear(st));
-  PC_TRY(ee_fill_ctx(&e->geom, symbols, e->ctx, -e->bias, st));
-  PC_TRY(ee_halo_bulk(&e->geom, e->ctx, e->ngroup, e->nimg, st));
-  const std::vector<int32_t> &step_row = e->step_row;  // rows are laid out [step][img][l]
-  const size_t row = step_row[e->nsteps];
-  if (e->stepwise_encoder) {
-    for (int s = 0; s < e->nsteps; s++) {
-      const Window cur = e->window(s);
-      PC_TRY(e->network_step(s, cur, st));
-      PC_TRY(ee_tables(&e->geom, e->act[kLayers - 1], symbols, e->tables_d + (size_t)step_row[s] * cols,
-                       e->labels_d + step_row[s], cur.lo, cur.len, s, e->nlevels, e->bias, e->total, e->beta, st));
-    }
-  } else {
-    PC_TRY(e->network_bulk(st));
-    PC_TRY(ee_tables_bulk(&e->geom, e->act[kLayers - 1], symbols, e->tables_d, e->labels_d, e->nlevels, e->bias,
-                          e->total, e->beta, st));
-  }
-  HIP_TRY(hipMemcpyAsync(e->tables_h, e->tables_d, row * cols * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(e->labels_h, e->labels_d, row * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  PC_TRY(e->fork(caller));
+  for (Group &g : e->groups) PC_TRY(e->encode_tables(g, symbols));
   int status = 0;
-  for_each_image(e->nimg, [&](int img) {
-    pconv_coder *c = e->coders[img];
-    int rc = pconv_coder_start_encoder(c);
-    for (int s = 0; s < e->nsteps && rc >= 0; s++) {
-      const size_t len = (size_t)(step_row[s + 1] - step_row[s]) / e->nimg;
-      if (!len) continue;
-      const size_t r0 = (size_t)step_row[s] + (size_t)img * len;
-      rc = pconv_coder_encodes(c, e->tables_h + r0 * cols, e->nlevels, e->labels_h + r0, (int)len);
-    }
-    if (rc >= 0) rc = pconv_coder_end_encoder(c);
-    if (rc < 0) {
-      status = rc;
-      pconv_set_error("ee_encode: coder of image %d: %s", img, pconv_coder_error(c));
-      return;
-    }
-    size_t nb = 0;
-    const uint8_t *p = pconv_coder_bytes(c, &nb);
-    e->streams[img].assign(p, p + nb);
-  });
+  // the first group's frames are coded while the GPU still works on the second's
+  for (Group &g : e->groups) {
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for_each_image(g.nimg, [&](int i) {
+      const int img = g.first + i;
+      pconv_coder *c = e->coders[img];
+      int rc = pconv_coder_start_encoder(c);
+      for (int s = 0; s < e->nsteps && rc >= 0; s++) {
+        const size_t len = (size_t)(g.step_row[s + 1] - g.step_row[s]) / g.nimg;
+        if (!len) continue;
+        const size_t r0 = (size_t)g.step_row[s] + (size_t)i * len;
+        rc = pconv_coder_encodes(c, g.tables_h + r0 * cols, e->nlevels, g.labels_h + r0, (int)len);
+      }
+      if (rc >= 0) rc = pconv_coder_end_encoder(c);
+      if (rc < 0) {
+        status = rc;
+        pconv_set_error("ee_encode: coder of image %d: %s", img, pconv_coder_error(c));
+        return;
+      }
+      size_t nb = 0;
+      const uint8_t *p = pconv_coder_bytes(c, &nb);
+      e->streams[img].assign(p, p + nb);
+    });
+  }
+  PC_TRY(e->join(caller));
   return status < 0 ? PCONV_EINVAL : PCONV_OK;
 }
 
@@ -364,45 +535,56 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
                     float *symbols_out, void *stream) {
   PCONV_REQUIRE(e && streams && nbytes && symbols_out, "ee_decode: bad argument");
   for (int l = 0; l < kLayers; l++) PCONV_REQUIRE(e->bound[l], "ee_decode: layer %d has no weights", l);
-  hipStream_t st = as_stream(stream);
-  const int cols = e->nlevels + 1;
+  hipStream_t caller = as_stream(stream);
   for (int i = 0; i < e->nimg; i++)
     if (pconv_coder_start_decoder_mem(e->coders[i], streams[i], nbytes[i]) < 0) {
       pconv_set_error("ee_decode: cannot start decoder %d", i);
       return PCONV_EINVAL;
     }
-  PC_TRY(e->clear(st));
+  // PCONV_ENGINE_TIMING=1: where the decoder's wall time goes, printed once per call
+  const bool timing = getenv("PCONV_ENGINE_TIMING") != nullptr;
+  double t_wait = 0, t_coder = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  PC_TRY(e->fork(caller));
+  for (Group &g : e->groups) g.pool = new StepPool(g.nimg);
+  int rc = PCONV_OK;
+  for (Group &g : e->groups)
+    if (rc >= 0) rc = e->clear(g);
+  // ping-pong: while the host decodes step s-1 of one group, the GPU runs the
+  // other group's step; a group's step s is queued as soon as its step s-1 symbols are back
   Window prev = {0, 0, 0, 0};
-  std::vector<int32_t> sym;
-  int status = 0;
-  for (int s = 0; s < e->nsteps; s++) {
-    const Window cur = e->window(s);
-    if (s > 0) PC_TRY(ee_scatter(&e->geom, e->packed, e->ctx, prev.lo, prev.len, s - 1, -e->bias, st));
-    if (cur.len > 0) {
-      const size_t rows = (size_t)cur.len * e->nimg;
-      PC_TRY(e->network_step(s, cur, st));
-      PC_TRY(ee_tables(&e->geom, e->act[kLayers - 1], nullptr, e->tables_d, nullptr, cur.lo, cur.len, s, e->nlevels,
-                       e->bias, e->total, e->beta, st));
-      HIP_TRY(hipMemcpyAsync(e->tables_h, e->tables_d, rows * cols * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      sym.resize(rows);
-      for_each_image(e->nimg, [&](int img) {
-        int rc = pconv_coder_decodes_i32(e->coders[img], e->tables_h + (size_t)img * cur.len * cols, e->nlevels,
-                                         sym.data() + (size_t)img * cur.len, cur.len);
-        if (rc < 0) status = rc;
-      });
-      if (status < 0) {
-        pconv_set_error("ee_decode: arithmetic decoder desynchronised at step %d", s);
-        return PCONV_EINVAL;
+  for (int s = 0; s <= e->nsteps && rc >= 0; s++) {
+    const Window cur = s < e->nsteps ? e->window(s) : Window{0, 0, 0, 0};
+    for (Group &g : e->groups) {
+      if (s > 0 && rc >= 0) rc = e->decode_symbols(g, s - 1, prev, &t_wait, &t_coder);
+      if (rc < 0) break;
+      if (s < e->nsteps) {
+        rc = e->decode_enqueue(g, s, prev, cur);
+      } else {
+        // the symbols of the last step have not been scattered by a following step yet
+        rc = ee_scatter(&g.geom, g.packed, g.ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, g.stream);
+        if (rc >= 0)
+          rc = ee_read_symbols(&g.geom, g.ctx, symbols_out + (size_t)g.first * e->image_symbols(), e->bias, g.stream);
       }
-      for (size_t i = 0; i < rows; i++) e->packed_h[i] = (float)sym[i];
-      HIP_TRY(hipMemcpyAsync(e->packed, e->packed_h, rows * 4, hipMemcpyHostToDevice, st));
     }
     prev = cur;
   }
-  // the symbols of the last step have not been scattered by a following step yet
-  PC_TRY(ee_scatter(&e->geom, e->packed, e->ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, st));
-  PC_TRY(ee_read_symbols(&e->geom, e->ctx, symbols_out, e->bias, st));
+  for (Group &g : e->groups) {
+    delete g.pool;
+    g.pool = nullptr;
+  }
+  if (rc < 0) {
+    for (Group &g : e->groups) (void)hipStreamSynchronize(g.stream);
+    return rc;
+  }
+  PC_TRY(e->join(caller));
+  if (timing) {
+    const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    fprintf(stderr,
+            "[pconv engine] decode %d frame(s) in %d group(s), %d steps: host loop %.1f ms, of which GPU wait %.1f ms, "
+            "coder %.1f ms\n",
+            e->nimg, (int)e->groups.size(), e->nsteps, all * 1e3, t_wait * 1e3, t_coder * 1e3);
+  }
   return PCONV_OK;
 }
 
