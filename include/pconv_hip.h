@@ -189,6 +189,15 @@ int pconv_conv2d(const float *in, const float *packed_w, const float *bias, floa
                  int tn, int cin, int h, int w, int cout, int k, int stride, int act,
                  const float *slope, const int32_t *col_limit, int npart, void *stream);
 
+/* PseudoGDNV2.forward (PseudoContextV2.py:133-216) in one launch on the same
+ * kernel: out = in / sqrt(beta + gamma * in^2) over channels (inverse: in * sqrt),
+ * zeros from each tile's col_limit on (the reference's mask).  in, out
+ * (tn, ch, h, w), distinct; packed_gamma = pconv_conv_pack_weight of the effective
+ * (re-parametrised) gamma viewed as a (ch, ch, 1, 1) weight; beta (ch) effective. */
+int pconv_gdn(const float *in, const float *packed_gamma, const float *beta, float *out,
+              int tn, int ch, int h, int w, int inverse, const int32_t *col_limit, int npart,
+              void *stream);
+
 /* ------------------------------------------------------------------------
  * Device kernels -- entropy wavefront (one call = one step of one op)
  * `order`/`plane_start` come from pconv_host_wavefront; lo/hi = the range of

@@ -879,6 +879,19 @@ conv_probe = None
 _VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack
 
 
+def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0):
+    """PseudoGDNV2.forward in one launch: x / sqrt(beta + gamma x^2) (inverse: x * sqrt),
+    zeros from each tile's col_limit on.  gamma (ch, ch), beta (ch): effective values."""
+    _require_gpu(x, "tile_gdn")
+    tn, ch, h, w = x.shape
+    stream = _stream(x.device)
+    packed = packed_conv_weight(owner, gamma.view(ch, ch, 1, 1), stream)
+    out = torch.empty_like(x)
+    call("pconv_gdn", _ptr(x), _ptr(packed), _ptr(beta.detach().contiguous()), _ptr(out), tn, ch, h, w,
+         1 if inverse else 0, _ptr(col_limit), int(npart), stream)
+    return out
+
+
 def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0):
     """y = conv2d(x, weight, bias, stride) (+ PReLU(slope)), no padding, on the
     fp32 matrix cores.  x (tn, cin, h, w) -> (tn, cout, ho, wo)."""

@@ -171,6 +171,7 @@ class PseudoGDNV2(nn.Module):
         self.reparam_offset = torch.FloatTensor([reparam_offset])
         self.trim = PseudoFillV2(0, npart, ctx, device=device)
         self.mask = None
+        self.__dict__["ctx"] = ctx  # not a sub-module: owned by the codec
         gid = device if isinstance(device, int) else device[0]
         self.build(ch, torch.device(backend.device_of(gid)))
 
@@ -188,7 +189,27 @@ class PseudoGDNV2(nn.Module):
             return
         self.mask = self.trim(torch.ones_like(x).detach())
 
+    def effective(self):
+        """(gamma, beta) after the lower-bound re-parametrisation, cached until a
+        parameter changes"""
+        key = (self.gamma._version, self.beta._version, self.gamma.device)
+        if getattr(self, "_effective", (None,))[0] != key:
+            with torch.no_grad():
+                pedestal = self.pedestal.to(self.gamma.device)
+                beta = LowerBound.apply(self.beta, self.beta_bound) ** 2 - pedestal
+                gamma = LowerBound.apply(self.gamma, self.gamma_bound) ** 2 - pedestal
+            self._effective = (key, gamma.contiguous(), beta.contiguous())
+        return self._effective[1], self._effective[2]
+
     def forward(self, inputs):
+        ops = backend.ops()
+        if hasattr(ops, "tile_gdn") and inputs.is_cuda and not torch.is_grad_enabled():
+            # one launch on the tile-convolution kernel (squares, 1x1 MFMA GEMM, sqrt,
+            # divide and the valid-column mask fused)
+            gamma, beta = self.effective()
+            ctx_op = self.ctx.native(inputs)
+            limit, npart = ops.conv_col_limit(ctx_op, inputs.shape[2], inputs.shape[3], 0, inputs)
+            return ops.tile_gdn(self, inputs.contiguous(), gamma, beta, self.inverse, limit, npart)
         self.pedestal = self.pedestal.to(inputs.device)
         ch = inputs.size(1)
         self.setup_mask(inputs)

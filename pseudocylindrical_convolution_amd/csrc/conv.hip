@@ -60,8 +60,10 @@ struct ConvCfg {
   static_assert(BM % 4 == 0, "weight slab rows are float4 multiples");
 };
 
-// act: 0 none, 1 PReLU(slope per cout)
-template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
+// act: 0 none, 1 PReLU(slope per cout), 2 / 3 GDN / inverse GDN (with SQ: the 1x1
+// "convolution" runs on the squared input, out = x / sqrt(acc + beta) or
+// x * sqrt(acc + beta) inside the valid columns, 0 outside)
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
     const float *__restrict__ slope, float *__restrict__ out, int cin, int h, int w, int cout,
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     const int xoff = half ? offb : offa;                                                     \
     const int woff = (2 * (KP) + half) * C::BM + wbase;                                      \
     _Pragma("unroll") for (int m = 0; m < MT; m++) A[m] = ws[woff + m * 32];                 \
-    _Pragma("unroll") for (int n = 0; n < NT; n++) B[n] = xs[xbase[n] + xoff];               \
+    _Pragma("unroll") for (int n = 0; n < NT; n++) {                                         \
+      B[n] = xs[xbase[n] + xoff];                                                            \
+      if (SQ) B[n] = B[n] * B[n];                                                            \
+    }                                                                                        \
   }
 #define PCONV_MFMA_BLOCK(A, B)                                                               \
   {                                                                                          \
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     __syncthreads();
   }
 
+  const int gdn_limit = (act >= 2 && col_limit) ? col_limit[t % npart] : wo;
   // epilogue: + bias, activation, store.  reg r of a 32x32 tile: cout row
   // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
 #pragma unroll
@@ -257,6 +263,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
         if (orow < ho && ocol < wo) {
           float v = acc[m][n][r] + bco;
           if (act == 1 && v < 0) v = v * sl;
+          if (act >= 2) {
+            // 1x1, stride 1: input and output share their geometry
+            const float xv = inp[((size_t)co * h + orow) * w + ocol];
+            const float nrm = sqrtf(v);
+            v = (ocol < gdn_limit) ? (act == 2 ? xv / nrm : xv * nrm) : 0.f;
+          }
           outp[((size_t)co * ho + orow) * wo + ocol] = v;
         }
       }
@@ -273,7 +285,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
   packed[i] = (co < cout && kk < red) ? w[(size_t)co * red + kk] : 0.f;
 }
 
-template <int MT, int NT, int WM, int WN, int KS, int S, int KC>
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ = false>
 int launch_conv(const float *in, const float *wp, const float *bias, const float *slope, float *out,
                 int tn, int cin, int h, int w, int cout, int cout_pad, int ho, int wo, int act,
                 const int32_t *col_limit, int npart, hipStream_t stream) {
@@ -289,7 +301,7 @@ int launch_conv(const float *in, const float *wp, const float *bias, const float
     return PCONV_EINVAL;
   }
   const size_t smem = (size_t)2 * C::STAGE * sizeof(float);
-  auto kern = conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC>;
+  auto kern = conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>;
   static bool raised = false;
   if (smem > 64 * 1024 && !raised) {
     raised = true;
@@ -371,5 +383,36 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
 #undef ARGS
   if (rc != PCONV_OK) return rc;
   PCONV_LAUNCH_CHECK("conv2d");
+  return PCONV_OK;
+}
+
+// GDN / inverse GDN of PseudoGDNV2.forward (PseudoContextV2.py:133-216) as ONE launch:
+// norm = conv1x1(x^2, gamma) + beta on the matrix cores, then x / sqrt(norm) (or
+// x * sqrt(norm)) in the epilogue, zeros past each tile's valid width.  The
+// reference runs it as mask, square, conv, sqrt, three mask blends and a divide --
+// eight passes over the activation.
+extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float *beta, float *out, int tn,
+                         int ch, int h, int w, int inverse, const int32_t *col_limit, int npart,
+                         void *stream) {
+  PCONV_REQUIRE(in && packed_gamma && beta && out && in != out, "gdn: bad pointer");
+  PCONV_REQUIRE(tn > 0 && ch > 0 && h > 0 && w > 0, "gdn: bad shape");
+  PCONV_REQUIRE(!col_limit || npart > 0, "gdn: col_limit needs npart");
+  int cp, rp;
+  pconv_conv_packed_size(ch, ch, 1, &cp, &rp);
+  hipStream_t s = as_stream(stream);
+  const int act = inverse ? 3 : 2;
+  const float *slope = nullptr;
+  int rc;
+  if (ch > 96)
+    rc = launch_conv<3, 2, 2, 2, 1, 1, 16, true>(in, packed_gamma, beta, slope, out, tn, ch, h, w, ch, cp, h, w, act,
+                                                col_limit, npart, s);
+  else if (ch > 32)
+    rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, beta, slope, out, tn, ch, h, w, ch, cp, h, w, act,
+                                                col_limit, npart, s);
+  else
+    rc = launch_conv<1, 1, 1, 4, 1, 1, 16, true>(in, packed_gamma, beta, slope, out, tn, ch, h, w, ch, cp, h, w, act,
+                                                col_limit, npart, s);
+  if (rc != PCONV_OK) return rc;
+  PCONV_LAUNCH_CHECK("gdn");
   return PCONV_OK;
 }

@@ -185,7 +185,12 @@ struct pconv_entropy_engine {
     g.first = first;
     g.geom = base;
     g.geom.nimg = n;
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    // highest priority: the step kernels are short and latency-bound.  (Measured:
+    // priority alone does not protect them -- running another chunk's transforms
+    // beside a decode doubled its GPU waits, so CodecEngine does not overlap them.)
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest));
     HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     g.step_row.assign(nsteps + 1, 0);
     for (int s = 0; s < nsteps; s++) g.step_row[s + 1] = g.step_row[s] + window(s).len * n;

@@ -296,3 +296,29 @@ def test_tile_conv_dead_column_skip():
         first_dead = ((int(limit[t]) + 63) // 64) * 64 if limit[t] > 0 else 0
         assert torch.equal(y[t, :, :, :first_dead], ref[t, :, :, :first_dead])
         assert y[t, :, :, first_dead:].abs().max().item() == 0 if first_dead < 256 else True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_fused_matches_reference_formula(hip_backend, inverse):
+    """PseudoGDNV2 on the GPU (one fused launch) against the reference's op-by-op
+    formula (PseudoContextV2.py:133-216) evaluated with torch on the same device"""
+    import torch
+    from pseudocylindrical_convolution_amd.PCONV_operator import PseudoContextV2, PseudoGDNV2
+    torch.manual_seed(3)
+    ctx = PseudoContextV2(16, True, device=0)
+    gdn = PseudoGDNV2(192, 16, ctx, 0, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(torch.rand_like(gdn.gamma) * 0.02)
+        gdn.beta.add_(torch.rand_like(gdn.beta) * 0.1)
+    x = torch.randn(16, 192, 8, 256, device="cuda")
+    ctx.setup_context(256)
+    with torch.no_grad():
+        fused = gdn(x)
+    with torch.enable_grad():
+        plain = gdn(x).detach()  # autograd on: the reference formula
+    assert fused.shape == plain.shape
+    assert torch.allclose(fused, plain, rtol=1e-5, atol=1e-6), (fused - plain).abs().max()
+    # dead columns are zero, the valid ones are not
+    w0 = int(ctx.produce_fill_param(0, 8, 256)[0])
+    assert fused[0, :, :, w0:].abs().sum() == 0 and fused[0, :, :, :w0].abs().sum() > 0
