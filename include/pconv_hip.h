@@ -176,18 +176,23 @@ int pconv_gmm_loss(const float *weight, const float *delta, const float *mean,
  * sites of model_zoo_v2.py:41-45,83-86,100-105,119,143,158-164,181,205; cuDNN in
  * the reference).  in (tn, cin, h, w); packed_w from pconv_conv_pack_weight;
  * out (tn, cout, ho, wo), ho = (h - k)/stride + 1, no implicit padding.
- * k in {1,3}, stride in {1,2}.  act: 0 none, 1 PReLU(slope[cout]).
+ * k in {1,3}, stride in {1,2}.  act: 0 none, 1 PReLU(slope[cout]), 4 sigmoid.
  * col_limit (may be NULL): per latitude tile (t % npart) the first dead output
  * column; 64-column tiles starting at or beyond it are written as zeros without
  * being computed.
  * Every output is one k-ascending fp32 fmaf chain from 0 (k = (ci*k + kh)*k + kw),
- * then + bias, then the activation. */
+ * then + bias, then the activation; then, each optional and in this order,
+ * * gate[.], + residual[.] (both shaped like out, may be NULL: the attention
+ * product and the residual sum that follow the convolution in
+ * model_zoo_v2.py:53,76,93,114,175) and, with trim != 0, zero from col_limit on
+ * (the PseudoFill that ends every block). */
 int pconv_conv_packed_size(int cout, int cin, int k, int *cout_pad, int *red_pad);
 int pconv_conv_pack_weight(const float *w, float *packed, int cout, int cin, int k,
                            void *stream);
 int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
                  int tn, int cin, int h, int w, int cout, int k, int stride, int act,
-                 const float *slope, const int32_t *col_limit, int npart, void *stream);
+                 const float *slope, const int32_t *col_limit, int npart,
+                 const float *residual, const float *gate, int trim, void *stream);
 
 /* PseudoGDNV2.forward (PseudoContextV2.py:133-216) in one launch on the same
  * kernel: out = in / sqrt(beta + gamma * in^2) over channels (inverse: in * sqrt),
@@ -196,6 +201,7 @@ int pconv_conv2d(const float *in, const float *packed_w, const float *bias, floa
  * (re-parametrised) gamma viewed as a (ch, ch, 1, 1) weight; beta (ch) effective. */
 int pconv_gdn(const float *in, const float *packed_gamma, const float *beta, float *out,
               int tn, int ch, int h, int w, int inverse, const int32_t *col_limit, int npart,
+              const float *residual /* added inside the valid columns, may be NULL */,
               void *stream);
 
 /* ------------------------------------------------------------------------

@@ -879,22 +879,38 @@ conv_probe = None
 _VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack
 
 
-def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0):
-    """PseudoGDNV2.forward in one launch: x / sqrt(beta + gamma x^2) (inverse: x * sqrt),
-    zeros from each tile's col_limit on.  gamma (ch, ch), beta (ch): effective values."""
+def _like_output(t, out, what):
+    if t is None:
+        return None
+    if tuple(t.shape) != tuple(out.shape) or t.device != out.device or t.dtype != torch.float32:
+        raise PconvError("%s: expected a float32 tensor shaped like the output %s, got %s"
+                         % (what, tuple(out.shape), tuple(t.shape)))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=None):
+    """PseudoGDNV2.forward in one launch: x / sqrt(beta + gamma x^2) (inverse: x * sqrt)
+    (+ residual), zeros from each tile's col_limit on.  gamma (ch, ch), beta (ch):
+    effective values."""
     _require_gpu(x, "tile_gdn")
     tn, ch, h, w = x.shape
     stream = _stream(x.device)
     packed = packed_conv_weight(owner, gamma.view(ch, ch, 1, 1), stream)
     out = torch.empty_like(x)
+    residual = _like_output(residual, out, "tile_gdn: residual")
     call("pconv_gdn", _ptr(x), _ptr(packed), _ptr(beta.detach().contiguous()), _ptr(out), tn, ch, h, w,
-         1 if inverse else 0, _ptr(col_limit), int(npart), stream)
+         1 if inverse else 0, _ptr(col_limit), int(npart), _ptr(residual), stream)
     return out
 
 
-def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0):
-    """y = conv2d(x, weight, bias, stride) (+ PReLU(slope)), no padding, on the
-    fp32 matrix cores.  x (tn, cin, h, w) -> (tn, cout, ho, wo)."""
+FUSED_EPILOGUE = True  # tile_conv2d takes sigmoid / gate / residual / trim
+
+
+def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0, sigmoid=False, gate=None,
+                residual=None, trim=False):
+    """y = conv2d(x, weight, bias, stride), no padding, on the fp32 matrix cores, then in
+    the same launch PReLU(slope) or sigmoid, * gate, + residual, and (trim) zeros from
+    each tile's col_limit on.  x (tn, cin, h, w) -> (tn, cout, ho, wo)."""
     _require_gpu(x, "tile_conv2d")
     tn, cin, h, w = x.shape
     cout, cin_w, k, k2 = weight.shape
@@ -908,9 +924,14 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(x.device))
+    if sigmoid and slope is not None:
+        raise PconvError("tile_conv2d: PReLU and sigmoid are exclusive")
+    gate = _like_output(gate, out, "tile_conv2d: gate")
+    residual = _like_output(residual, out, "tile_conv2d: residual")
     call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
-         tn, cin, h, w, cout, k, int(stride), 1 if slope is not None else 0,
-         _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart), stream)
+         tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
+         _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
+         _ptr(residual), _ptr(gate), 1 if trim else 0, stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         tile = "192" if cout > 96 else ("96" if cout > 32 else "32")

@@ -201,15 +201,24 @@ class PseudoGDNV2(nn.Module):
             self._effective = (key, gamma.contiguous(), beta.contiguous())
         return self._effective[1], self._effective[2]
 
-    def forward(self, inputs):
+    def forward(self, inputs, residual=None, trim=None):
+        """reference signature: forward(inputs).  residual / trim (a PseudoFill module):
+        the `trim(residual + gdn(inputs))` that ends ResidualBlockDown / ResidualBlockUp,
+        evaluated in the same launch when the backend can."""
         ops = backend.ops()
         if hasattr(ops, "tile_gdn") and inputs.is_cuda and not torch.is_grad_enabled():
             # one launch on the tile-convolution kernel (squares, 1x1 MFMA GEMM, sqrt,
-            # divide and the valid-column mask fused)
+            # divide, residual and the valid-column mask fused)
             gamma, beta = self.effective()
             ctx_op = self.ctx.native(inputs)
             limit, npart = ops.conv_col_limit(ctx_op, inputs.shape[2], inputs.shape[3], 0, inputs)
-            return ops.tile_gdn(self, inputs.contiguous(), gamma, beta, self.inverse, limit, npart)
+            return ops.tile_gdn(self, inputs.contiguous(), gamma, beta, self.inverse, limit, npart, residual)
+        out = self._formula(inputs)
+        if residual is not None:
+            out = residual + out
+        return trim(out) if trim is not None else out
+
+    def _formula(self, inputs):
         self.pedestal = self.pedestal.to(inputs.device)
         ch = inputs.size(1)
         self.setup_mask(inputs)

@@ -60,15 +60,30 @@ struct ConvCfg {
   static_assert(BM % 4 == 0, "weight slab rows are float4 multiples");
 };
 
-// act: 0 none, 1 PReLU(slope per cout), 2 / 3 GDN / inverse GDN (with SQ: the 1x1
-// "convolution" runs on the squared input, out = x / sqrt(acc + beta) or
-// x * sqrt(acc + beta) inside the valid columns, 0 outside)
+// What happens to an accumulator on its way out:  v = acc + bias;
+//   act 1: PReLU(slope per cout)   act 4: sigmoid
+//   act 2 / 3: GDN / inverse GDN (with SQ: the 1x1 "convolution" ran on the squared
+//              input): v = x / sqrt(v) or x * sqrt(v), x = the input at the same place
+//   gate:      v = gate[.] * v        (attention: trunk * sigmoid(conv))
+//   residual:  v = residual[.] + v    (the "x + f(x)" of the residual blocks)
+//   trim:      v = 0 from the tile's col_limit on (PseudoFill of the block output)
+// gate and residual have the output's shape.  This replaces up to four
+// element-wise passes over the activation that follow the convolution in the
+// reference's graph (sigmoid, mul, add, fill).
+struct ConvEpilogue {
+  const float *bias, *slope, *residual, *gate;
+  const int32_t *col_limit;  // per latitude tile: first dead output column (may be null)
+  int npart, act, trim;
+};
+
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
-    const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
-    const float *__restrict__ slope, float *__restrict__ out, int cin, int h, int w, int cout,
-    int cout_pad, int ho, int wo, int act, int tiles_r, int tiles_c, int cblocks,
-    const int32_t *__restrict__ col_limit, int npart) {
+    const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
+    int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, ConvEpilogue ep) {
+  const float *__restrict__ bias = ep.bias;
+  const float *__restrict__ slope = ep.slope;
+  const int32_t *__restrict__ col_limit = ep.col_limit;
+  const int npart = ep.npart, act = ep.act;
   using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
   using P = typename C::P;
   constexpr int kThreads = C::THREADS;
@@ -245,8 +260,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     __syncthreads();
   }
 
-  const int gdn_limit = (act >= 2 && col_limit) ? col_limit[t % npart] : wo;
-  // epilogue: + bias, activation, store.  reg r of a 32x32 tile: cout row
+  const int trim_at = ((ep.trim || act == 2 || act == 3) && col_limit) ? col_limit[t % npart] : wo;
+  const size_t tile_out = (size_t)t * cout * ho * wo;
+  const float *resp = ep.residual ? ep.residual + tile_out : nullptr;
+  const float *gatep = ep.gate ? ep.gate + tile_out : nullptr;
+  // epilogue (see ConvEpilogue).  reg r of a 32x32 tile: cout row
   // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
 #pragma unroll
   for (int m = 0; m < MT; m++) {
@@ -261,15 +279,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
         const int seg = wn * NT + n;
         const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
         if (orow < ho && ocol < wo) {
+          const size_t oi = ((size_t)co * ho + orow) * wo + ocol;
           float v = acc[m][n][r] + bco;
-          if (act == 1 && v < 0) v = v * sl;
-          if (act >= 2) {
+          if (act == 1) {
+            if (v < 0) v = v * sl;
+          } else if (act == 2 || act == 3) {
             // 1x1, stride 1: input and output share their geometry
-            const float xv = inp[((size_t)co * h + orow) * w + ocol];
+            const float xv = inp[oi];
             const float nrm = sqrtf(v);
-            v = (ocol < gdn_limit) ? (act == 2 ? xv / nrm : xv * nrm) : 0.f;
+            v = act == 2 ? xv / nrm : xv * nrm;
+          } else if (act == 4) {
+            v = 1.f / (1.f + expf(-v));
           }
-          outp[((size_t)co * ho + orow) * wo + ocol] = v;
+          if (gatep) v = gatep[oi] * v;
+          if (resp) v = resp[oi] + v;
+          if (ocol >= trim_at) v = 0.f;
+          outp[oi] = v;
         }
       }
     }
@@ -286,9 +311,8 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
 }
 
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ = false>
-int launch_conv(const float *in, const float *wp, const float *bias, const float *slope, float *out,
-                int tn, int cin, int h, int w, int cout, int cout_pad, int ho, int wo, int act,
-                const int32_t *col_limit, int npart, hipStream_t stream) {
+int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout,
+                int cout_pad, int ho, int wo, const ConvEpilogue &ep, hipStream_t stream) {
   using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
   constexpr int kThreads = C::THREADS;
   constexpr int kTileRows = C::ROWS;
@@ -312,9 +336,8 @@ int launch_conv(const float *in, const float *wp, const float *bias, const float
       return PCONV_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, bias, slope,
-                     out, cin, h, w, cout, cout_pad, ho, wo, act, tiles_r, tiles_c, cblocks,
-                     col_limit, npart);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, out, cin, h, w, cout,
+                     cout_pad, ho, wo, tiles_r, tiles_c, cblocks, ep);
   return PCONV_OK;
 }
 
@@ -346,19 +369,22 @@ extern "C" int pconv_conv_pack_weight(const float *w, float *packed, int cout, i
 extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
                             int tn, int cin, int h, int w, int cout, int k, int stride, int act,
                             const float *slope, const int32_t *col_limit, int npart,
-                            void *stream) {
+                            const float *residual, const float *gate, int trim, void *stream) {
   PCONV_REQUIRE(in && packed_w && out, "conv2d: null pointer");
   PCONV_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv2d: k=%d stride=%d unsupported",
                 k, stride);
   PCONV_REQUIRE(h >= k && w >= k && tn > 0 && cin > 0 && cout > 0, "conv2d: bad shape");
-  PCONV_REQUIRE(act == 0 || (act == 1 && slope), "conv2d: bad activation");
+  PCONV_REQUIRE(act == 0 || (act == 1 && slope) || act == 4, "conv2d: bad activation %d", act);
   PCONV_REQUIRE(!col_limit || npart > 0, "conv2d: col_limit needs npart");
+  PCONV_REQUIRE(!trim || col_limit, "conv2d: trim needs col_limit");
+  PCONV_REQUIRE(residual != out && gate != out, "conv2d: residual / gate must not alias the output");
   const int ho = (h - k) / stride + 1, wo = (w - k) / stride + 1;
   int cp, rp;
   pconv_conv_packed_size(cout, cin, k, &cp, &rp);
   hipStream_t s = as_stream(stream);
+  const ConvEpilogue ep = {bias, slope, residual, gate, col_limit, npart, act, trim};
   int rc;
-#define ARGS in, packed_w, bias, slope, out, tn, cin, h, w, cout, cp, ho, wo, act, col_limit, npart, s
+#define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, ep, s
   // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):
   //   cout > 96 : 192 couts x (2 rows x 64 px), 4 waves of 96 x 64
   //   cout > 32 :  96 couts x (4 rows x 64 px), 8 waves of 96 x 32
@@ -388,30 +414,26 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
 
 // GDN / inverse GDN of PseudoGDNV2.forward (PseudoContextV2.py:133-216) as ONE launch:
 // norm = conv1x1(x^2, gamma) + beta on the matrix cores, then x / sqrt(norm) (or
-// x * sqrt(norm)) in the epilogue, zeros past each tile's valid width.  The
-// reference runs it as mask, square, conv, sqrt, three mask blends and a divide --
-// eight passes over the activation.
+// x * sqrt(norm)) in the epilogue, (+ residual,) zeros past each tile's valid width.
+// The reference runs it as mask, square, conv, sqrt, three mask blends and a divide
+// -- eight passes over the activation.
 extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float *beta, float *out, int tn,
                          int ch, int h, int w, int inverse, const int32_t *col_limit, int npart,
-                         void *stream) {
-  PCONV_REQUIRE(in && packed_gamma && beta && out && in != out, "gdn: bad pointer");
+                         const float *residual, void *stream) {
+  PCONV_REQUIRE(in && packed_gamma && beta && out && in != out && residual != out, "gdn: bad pointer");
   PCONV_REQUIRE(tn > 0 && ch > 0 && h > 0 && w > 0, "gdn: bad shape");
   PCONV_REQUIRE(!col_limit || npart > 0, "gdn: col_limit needs npart");
   int cp, rp;
   pconv_conv_packed_size(ch, ch, 1, &cp, &rp);
   hipStream_t s = as_stream(stream);
-  const int act = inverse ? 3 : 2;
-  const float *slope = nullptr;
+  const ConvEpilogue ep = {beta, nullptr, residual, nullptr, col_limit, npart, inverse ? 3 : 2, 1};
   int rc;
   if (ch > 96)
-    rc = launch_conv<3, 2, 2, 2, 1, 1, 16, true>(in, packed_gamma, beta, slope, out, tn, ch, h, w, ch, cp, h, w, act,
-                                                col_limit, npart, s);
+    rc = launch_conv<3, 2, 2, 2, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, ep, s);
   else if (ch > 32)
-    rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, beta, slope, out, tn, ch, h, w, ch, cp, h, w, act,
-                                                col_limit, npart, s);
+    rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, ep, s);
   else
-    rc = launch_conv<1, 1, 1, 4, 1, 1, 16, true>(in, packed_gamma, beta, slope, out, tn, ch, h, w, ch, cp, h, w, act,
-                                                col_limit, npart, s);
+    rc = launch_conv<1, 1, 1, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, ep, s);
   if (rc != PCONV_OK) return rc;
   PCONV_LAUNCH_CHECK("gdn");
   return PCONV_OK;

@@ -46,34 +46,54 @@ class ClipData(nn.Module):
 
 class TileConv2d(nn.Conv2d):
     """nn.Conv2d (no padding, k in {1,3}, stride in {1,2}) evaluated by the
-    backend's tile convolution.  `fuse(x, prelu)` folds a following nn.PReLU into
-    the kernel epilogue.  `live=(ctx, base)` tells the kernel which output columns
-    can ever be read: tile t only needs columns < widths_t(base) + (wo - base),
-    base = tile width of the scale the output lives in; 64-column blocks beyond
-    that are written as zeros without being computed (they are dead: every
-    consumer either trims them or never reads them).
-    PCONV_TILE_CONV=vendor routes to torch's own conv for A/B timing on the GPU
-    (never used for parity claims)."""
+    backend's tile convolution, with what follows it in the graph folded into the
+    kernel's epilogue when the backend can:
+      prelu / sigmoid   the activation module that follows
+      gate              y = gate * y          (attention: trunk * sigmoid(conv))
+      residual          y = residual + y      (x + f(x) of the residual blocks)
+      trim              the PseudoFill module that ends the block
+    `live=(ctx, base)` tells the kernel which output columns can ever be read: tile t
+    only needs columns < widths_t(base) + (wo - base), base = tile width of the
+    scale the output lives in; 64-column blocks beyond that are written as zeros
+    without being computed (they are dead: every consumer either trims them or
+    never reads them).  Without fusion support (CPU oracle backend,
+    PCONV_TILE_CONV=vendor for A/B timing -- never used for parity claims) the same
+    operations run one by one, in the same order."""
 
-    def _native(self, x, prelu, live=None):
+    def _native(self, x, prelu=None, live=None, sigmoid=False, gate=None, residual=None, trim=None):
         ops = backend.ops()
         slope = prelu.weight if prelu is not None else None
-        if os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d"):
-            y = nn.functional.conv2d(x, self.weight, self.bias, self.stride)
-            return nn.functional.prelu(y, slope) if slope is not None else y
+        vendor = os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d")
+        fused = (not vendor) and getattr(ops, "FUSED_EPILOGUE", False)
         limit, npart = None, 0
         if live is not None and hasattr(ops, "conv_col_limit") and os.environ.get("PCONV_SKIP_DEAD", "1") == "1":
             ctx, base = live
             k, s = self.kernel_size[0], self.stride[0]
             wo = (x.shape[3] - k) // s + 1
             limit, npart = ops.conv_col_limit(ctx.native(x), x.shape[2], base, wo - base, x)
-        return ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope, limit, npart)
+            if trim is not None and wo != base:
+                raise ValueError("trim on an output that still carries halo columns")
+        if fused and (trim is None or limit is not None):
+            return ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope, limit, npart,
+                                   sigmoid=sigmoid, gate=gate, residual=residual, trim=trim is not None)
+        if vendor:
+            y = nn.functional.conv2d(x, self.weight, self.bias, self.stride)
+            y = nn.functional.prelu(y, slope) if slope is not None else y
+        else:
+            y = ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope, limit, npart)
+        if sigmoid:
+            y = torch.sigmoid(y)
+        if gate is not None:
+            y = gate * y
+        if residual is not None:
+            y = residual + y
+        return trim(y) if trim is not None else y
 
-    def forward(self, x, live=None):
-        return self._native(x, None, live)
+    def forward(self, x, live=None, **epilogue):
+        return self._native(x, None, live, **epilogue)
 
-    def fuse(self, x, prelu, live=None):
-        return self._native(x, prelu, live)
+    def fuse(self, x, prelu, live=None, **epilogue):
+        return self._native(x, prelu, live, **epilogue)
 
 
 def _conv(cin, cout, k, stride=1):
@@ -99,7 +119,7 @@ class ResidualBlock(nn.Module):
         live = (self.ctx, x.shape[3])
         y = self.conv1.fuse(self.pad(x), self.relu1, live)
         y = self.conv2.fuse(y, self.relu2, live)
-        return self.trim(x + self.conv3(y, live))
+        return self.conv3(y, live, residual=x, trim=self.trim)
 
 
 class AttentionBlock(nn.Module):
@@ -114,10 +134,13 @@ class AttentionBlock(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
+        # x + trunk(x) * sigmoid(conv(...)): the sigmoid (attention[4]), the product, the
+        # sum and the trim run in the epilogue of the 1x1 conv (attention[3])
         a = x
-        for i, m in enumerate(self.attention):
-            a = m(a, (self.ctx, x.shape[3])) if i == 3 else m(a)
-        return self.trim(x + self.trunk(x) * a)
+        for m in self.attention[:3]:
+            a = m(a)
+        return self.attention[3](a, (self.ctx, x.shape[3]), sigmoid=True, gate=self.trunk(x), residual=x,
+                                 trim=self.trim)
 
 
 class ResidualBlockV2(nn.Module):
@@ -136,8 +159,7 @@ class ResidualBlockV2(nn.Module):
     def forward(self, x):
         live = (self.ctx, x.shape[3])
         y = self.conv1.fuse(self.pad(x), self.relu1, live)
-        y = self.conv2.fuse(y, self.relu2, live)
-        return self.trim(x + y)
+        return self.conv2.fuse(y, self.relu2, live, residual=x, trim=self.trim)
 
 
 class ResidualBlockDown(nn.Module):
@@ -159,8 +181,7 @@ class ResidualBlockDown(nn.Module):
         live = (self.ctx, x.shape[3] // 2)
         t = self.short_cut(x, live)
         y = self.conv1.fuse(self.pad1(x), self.relu1, live)
-        y = self.relu2(self.conv2(self.pad2(y), live))
-        return self.trim(t + y)
+        return self.relu2(self.conv2(self.pad2(y), live), residual=t, trim=self.trim)
 
 
 class SphereConv2(nn.Module):
@@ -174,7 +195,7 @@ class SphereConv2(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.trim(self.conv(self.pad(x), (self.ctx, x.shape[3] // 2)))
+        return self.conv(self.pad(x), (self.ctx, x.shape[3] // 2), trim=self.trim)
 
 
 class EncoderV2(nn.Module):
@@ -195,9 +216,9 @@ class EncoderV2(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        for i, m in enumerate(self.net):
-            x = m(x, (self.ctx, x.shape[3])) if i == len(self.net) - 1 else m(x)
-        return self.trim(self.act(x))
+        for m in self.net[:-1]:
+            x = m(x)
+        return self.net[-1](x, (self.ctx, x.shape[3]), sigmoid=True, trim=self.trim)  # self.act fused
 
 
 class ResidualBlockUp(nn.Module):
@@ -220,9 +241,8 @@ class ResidualBlockUp(nn.Module):
     def forward(self, x):
         w = x.shape[3]
         br1 = self.dtow1(self.conv1.fuse(self.pad1(x), self.relu1, (self.ctx, w)))
-        br1 = self.relu2(self.conv2(self.pad2(br1), (self.ctx, 2 * w)))
         br2 = self.dtow2(self.short_cut(x, (self.ctx, w)))
-        return self.trim(br1 + br2)
+        return self.relu2(self.conv2(self.pad2(br1), (self.ctx, 2 * w)), residual=br2, trim=self.trim)
 
 
 class SphereConvOld(nn.Module):
@@ -235,7 +255,7 @@ class SphereConvOld(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.trim(self.conv(x, (self.ctx, x.shape[3])))
+        return self.conv(x, (self.ctx, x.shape[3]), trim=self.trim)
 
 
 class DecoderV2(nn.Module):
