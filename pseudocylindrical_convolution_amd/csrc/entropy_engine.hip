@@ -329,20 +329,21 @@ __global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
 }
 
 // Encoder ("bulk") form of the same layer: every symbol is known, so a position
-// can be evaluated for ALL its channel groups at once.  One wave per position
-// gathers the 5 x 5 x CIN window a single time, then walks the groups: the
-// workgroup stages the group's weight rows in LDS and every wave runs the masked
-// fmaf chain + butterfly for that group.  Per output the operations and their
-// order are exactly those of the step kernel above (psum = plane + group), so
-// encoder and decoder tables agree bit for bit.  Halos of the output are filled
-// afterwards by ee_halo_bulk.
-template <int CIN, int ITER, int BLOCK>
+// can be evaluated for ALL its channel groups at once.  A wave owns PP positions:
+// it gathers their 5 x 5 x CIN windows a single time, then walks the groups -- the
+// workgroup stages the group's weight rows in LDS, every lane reads its taps'
+// weights once (causally masked taps as zeros) and feeds the PP masked fmaf chains
+// + butterflies of its positions.  Per output the operations and their order are
+// exactly those of the step kernel above (psum = plane + group), so encoder and
+// decoder tables agree bit for bit.  Halos of the output are filled afterwards by
+// ee_halo_bulk.
+template <int CIN, int ITER, int BLOCK, int PP>
 __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
     float *__restrict__ y, int cout, int constrain, int pad_out) {
   constexpr int RED = CIN * KK;
-  constexpr int kPosPerWg = BLOCK / kWave;
+  constexpr int kPosPerWg = BLOCK / kWave * PP;
   __shared__ __attribute__((aligned(16))) float wl[slab_floats(CIN)];
   const int nchunk = (g.npos + kPosPerWg - 1) / kPosPerWg;
   const int chunk = blockIdx.x % nchunk;
@@ -350,65 +351,82 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   const int set = pn / g.nimg;
   const int group_in = CIN / g.ngroup;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  const int idx = chunk * kPosPerWg + wave;
-  const bool active = idx < g.npos;  // wave-uniform
-  const Pos p = decode_pos(g.order[active ? idx : 0], g.h, g.w);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int h = g.h, w = g.w;
   const int win = w + 2 * PAD;
   const int tile_elems = (h + 2 * PAD) * win * CIN;
   const int xi = shared_input ? pn % g.nimg : pn;
+  const float *ximg = x + (size_t)xi * g.npart * tile_elems;
   const int slack = (constrain == 5) ? 0 : 1;
-  float xv[ITER];
-  int lim[ITER];  // causal limit of the tap; very negative for lanes past the reduction length
+  const int idx0 = (chunk * (BLOCK / kWave) + wave) * PP;
+  unsigned off[ITER];  // byte offsets of this lane's taps inside a window
+  int lim[ITER];       // causal limit of the tap; very negative for lanes past the reduction length
   {
     TapWalk<CIN> tw(lane);
-    const float *xin = x + ((size_t)xi * g.npart + p.tg) * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
-      const int kk = lane + it * kWave;
-      const bool in = active && kk < RED;
+      const bool in = lane + it * kWave < RED;
       lim[it] = in ? tw.lim(group_in) : -(1 << 30);
-      xv[it] = in ? xin[tw.off(win)] : 0.f;
+      off[it] = in ? 4u * (unsigned)tw.off(win) : 0u;
       tw.next();
     }
   }
-  const size_t obase = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
-                        p.tw + pad_out) * cout;
+  float xv[PP][ITER];
+  size_t obase[PP];
+#pragma unroll
+  for (int j = 0; j < PP; j++) {
+    const int idx = idx0 + j < g.npos ? idx0 + j : 0;
+    const Pos p = decode_pos(__builtin_amdgcn_readfirstlane(g.order[idx]), h, w);
+    const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+      unsigned o = off[it];
+      asm volatile("" : "+v"(o));  // keeps the zero-extension out of a hoisted 64-bit add (see ee_conv_kernel)
+      xv[j][it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
+    }
+    obase[j] = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
+                p.tw + pad_out) * cout;
+  }
   for (int tc = 0; tc < g.ngroup; tc++) {
     __syncthreads();  // previous group's LDS reads are done
     stage_weights<CIN, BLOCK>(wl, wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN), threadIdx.x);
     __syncthreads();
     const int causal_base = (tc + slack) * group_in;
-    float acc[GO];
+    float acc[PP][GO];
 #pragma unroll
-    for (int o = 0; o < GO; o++) acc[o] = 0.f;
+    for (int j = 0; j < PP; j++)
+#pragma unroll
+      for (int o = 0; o < GO; o++) acc[j][o] = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
       const int kk = lane + it * kWave;
       const int kc = kk < RED ? kk : RED - 1;
-      const float xm = (lim[it] + causal_base > 0) ? xv[it] : 0.f;  // fmaf(0, w, acc) == acc
-      const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);
-      acc[0] = fmaf(xm, wv.x, acc[0]);
-      acc[1] = fmaf(xm, wv.y, acc[1]);
-      acc[2] = fmaf(xm, wv.z, acc[2]);
-    }
+      float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);
+      if (!(lim[it] + causal_base > 0)) wv = make_float4(0.f, 0.f, 0.f, 0.f);  // fmaf(x, 0, acc) == acc
 #pragma unroll
-    for (int o = 0; o < GO; o++) {
-      float v = acc[o];
-      for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-      acc[o] = v;
+      for (int j = 0; j < PP; j++) {
+        acc[j][0] = fmaf(xv[j][it], wv.x, acc[j][0]);
+        acc[j][1] = fmaf(xv[j][it], wv.y, acc[j][1]);
+        acc[j][2] = fmaf(xv[j][it], wv.z, acc[j][2]);
+      }
     }
-    if (active && lane < GO) {
-      float v = acc[0];
+    const int pout = tc * GO + (lane < GO ? lane : 0);
+    const int bidx = set * cout + pout;
+    const float bv = bias[bidx];
+    const float sv = slope ? slope[bidx] : 0.f;
 #pragma unroll
-      for (int o = 1; o < GO; o++) v = (lane == o) ? acc[o] : v;
-      const int pout = tc * GO + lane;
-      const int bidx = set * cout + pout;
-      v = v + bias[bidx];
-      if (slope && v < 0) v = v * slope[bidx];
-      if (residual) v = v + residual[obase + pout];
-      y[obase + pout] = v;
+    for (int j = 0; j < PP; j++) {
+#pragma unroll
+      for (int o = 0; o < GO; o++) acc[j][o] = butterfly_sum(acc[j][o]);
+      if (idx0 + j < g.npos && lane < GO) {
+        float v = acc[j][0];
+#pragma unroll
+        for (int o = 1; o < GO; o++) v = (lane == o) ? acc[j][o] : v;
+        v = v + bv;
+        if (slope && v < 0) v = v * sv;
+        if (residual) v = v + residual[obase[j] + pout];
+        y[obase[j] + pout] = v;
+      }
     }
   }
 }
@@ -577,12 +595,17 @@ int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float 
                  const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
                  void *stream) {
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv_bulk: cout must be 3 per group");
-  constexpr int kBlock = 1024;  // 16 positions share each staged weight slab
-  const long long nchunk = (g->npos + kBlock / kWave - 1) / (kBlock / kWave);
+  constexpr int kBlock = 1024;
+  // positions per wave (each staged weight slab then serves 16x as many): as many as
+  // fit 128 registers beside the window (ITER values per position)
+  const int iter = (cin * KK + kWave - 1) / kWave;
+  const int pp = iter <= 11 ? 4 : (iter <= 20 ? 3 : 1);
+  const long long per_wg = kBlock / kWave * pp;
+  const long long nchunk = (g->npos + per_wg - 1) / per_wg;
   const long long grid = (long long)3 * g->nimg * nchunk;
   PCONV_REQUIRE(grid > 0 && grid < (1LL << 31), "ee_conv_bulk: grid %lld out of range", grid);
 #define EE_BULK(CIN, ITER)                                                                                   \
-  hipLaunchKernelGGL((ee_conv_bulk_kernel<CIN, ITER, kBlock>), dim3((unsigned)grid), dim3(kBlock), 0,        \
+  hipLaunchKernelGGL((ee_conv_bulk_kernel<CIN, ITER, kBlock, (ITER <= 11 ? 4 : (ITER <= 20 ? 3 : 1))>), dim3((unsigned)grid), dim3(kBlock), 0,        \
                      as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
                      pad_out)
   if (cin == 14) {
