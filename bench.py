@@ -77,6 +77,22 @@ class ConvProbe(object):
         return per
 
 
+def pmc_traffic(avg_algorithmic_flops):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from
+    inside this process; profiles/round1_conv_pmc.json holds the rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE measurement (corrected as MI355X_MICROARCH.md prescribes) of
+    the half-resolution 192->192 3x3 launch, scaled here by flops to the average launch
+    of the timed steps (the kernel's bytes per flop do not depend on the image scale)."""
+    path = os.path.join(ROOT, "profiles", "round1_conv_pmc.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        pmc = json.load(f)
+    per_flop = pmc["bytes_per_launch"]["total_dead_skipped"] / (pmc["flops_all_columns"] * VALID_FRACTION)
+    return {"traffic": round(per_flop * avg_algorithmic_flops),
+            "traffic_source": "profiles/round1_conv_pmc.json (rocprofv3 --pmc, scaled by flops)"}
+
+
 def cpu_baseline(sample_h, sample_w):
     """CPU oracle port of the same encode+decode on one bounded frame"""
     from pseudocylindrical_convolution_amd.PCONV_operator import backend
@@ -105,7 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--frames-per-gpu", type=int, default=4,
+    ap.add_argument("--frames-per-gpu", type=int, default=8,
                     help="frames each rank codes per step, in lock-step through the entropy wavefront")
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed passes before the warm-up so that the caching allocator reaches steady state")
@@ -171,6 +187,7 @@ def main():
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel[%s]" % dom_key, "achieved": round(ach, 2),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                     "launches": n, "avg_launch_ms": round(tt / n * 1e3, 4), "traffic": None}
+            roof.update(pmc_traffic(fl / n))
         conv_s = sum(v[1] for v in per_kernel.values()) / max(args.steps, 1)
         out = {
             "metric": "ERP MPix/s enc+dec, 4096x2048 model-idx 3", "value": round(total_pix / elapsed / 1e6, 4),

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kConvBlock = 256;   // step kernel: 4 waves, one wavefront position per wave at a time
-constexpr int kPosPerWave = 4;    // positions a wave walks with its weights in registers
+constexpr int kPosPerWave = 4;    // positions a wave walks with its weights in registers (measured best of 1..8)
 // register cap of the step kernel: weights + offsets + window = 5 registers per tap
 // and lane, so wider layers get fewer, fatter waves
 constexpr int waves_per_eu(int iter) { return iter <= 20 ? 4 : (iter <= 40 ? 2 : 1); }

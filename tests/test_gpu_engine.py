@@ -87,3 +87,32 @@ def test_engine_detects_corrupt_stream(hip_backend):
     except PconvError:
         return  # decoder assertion fired
     assert not torch.equal(out, sym)
+
+
+def test_engine_full_size_properties(hip_backend):
+    """BASELINE size (4096x2048, 1.5 M symbols per frame): size-independent properties.
+    decode(encode(x)) returns exactly the coded symbols; two frames coded together
+    (two ping-pong groups) give the streams of the frames coded alone; a stream
+    decodes the same alone and beside another one; the reconstruction is finite,
+    in range and as close to the input as the reconstruction of the exact symbols."""
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = _codec()
+    eng = CodecEngine(56, 0, enc, dec)
+    H, W = 2048, 4096
+    x = _frames(2, H, W, seed=11)
+    sym = eng.symbols(x)
+    assert tuple(sym.shape) == (32, 14, 16, 512)
+    assert eng._engine("enc", 16, 512, 1).symbols_per_image == 14 * 16 * 16 * (836 * 512 // 1024)
+    both = eng.encode(x)
+    alone = [eng.encode(x[i:i + 1])[0] for i in range(2)]
+    assert both == alone
+    out2 = eng._engine("dec", 16, 512, 2).decode(both)
+    assert torch.equal(out2, sym)
+    out1 = eng._engine("dec", 16, 512, 1).decode([alone[1]])
+    assert torch.equal(out1, sym[16:])
+    # rate sanity: 8-level symbols cost at most 3 bits, and the model must not expand
+    for s in both:
+        assert 0 < len(s) * 8 < 3.2 * 14 * 16 * 16 * 418
+    rec = eng.decode(both, H, W)
+    assert tuple(rec.shape) == (2, 3, H, W) and torch.isfinite(rec).all()
+    assert torch.equal(rec, torch.cat([dec.reconstruct(sym[:16]), dec.reconstruct(sym[16:])], 0))
