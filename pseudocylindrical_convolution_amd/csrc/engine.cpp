@@ -498,9 +498,17 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
   hipStream_t caller = as_stream(stream);
   const int cols = e->nlevels + 1;
   PC_TRY(e->fork(caller));
-  for (Group &g : e->groups) PC_TRY(e->encode_tables(g, symbols));
+  // The bulk kernels fill the GPU on their own, so the groups run one after the
+  // other (not side by side like the decoder's latency-bound steps): the first
+  // group's tables are on the host half-way and its frames are coded on the CPU
+  // while the GPU works on the second group.
+  for (size_t k = 0; k < e->groups.size(); k++) {
+    Group &g = e->groups[k];
+    if (k > 0) HIP_TRY(hipStreamWaitEvent(g.stream, e->groups[k - 1].done, 0));
+    PC_TRY(e->encode_tables(g, symbols));
+    HIP_TRY(hipEventRecord(g.done, g.stream));
+  }
   int status = 0;
-  // the first group's frames are coded while the GPU still works on the second's
   for (Group &g : e->groups) {
     HIP_TRY(hipStreamSynchronize(g.stream));
     for_each_image(g.nimg, [&](int i) {

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     float *__restrict__ y, int cout, int constrain, int pad_out) {
   constexpr int RED = CIN * KK;
   constexpr int kPosPerWg = BLOCK / kWave * PP;
-  __shared__ __attribute__((aligned(16))) float wl[slab_floats(CIN)];
+  __shared__ __attribute__((aligned(16))) float wl2[2][slab_floats(CIN)];  // double-buffered weight slab
   const int nchunk = (g.npos + kPosPerWg - 1) / kPosPerWg;
   const int chunk = blockIdx.x % nchunk;
   const int pn = blockIdx.x / nchunk;  // replica-major image index, 0 .. 3*nimg
@@ -387,10 +387,15 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     obase[j] = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
                 p.tw + pad_out) * cout;
   }
+  stage_weights<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x);
+  __syncthreads();
   for (int tc = 0; tc < g.ngroup; tc++) {
-    __syncthreads();  // previous group's LDS reads are done
-    stage_weights<CIN, BLOCK>(wl, wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN), threadIdx.x);
-    __syncthreads();
+    // the next group's slab goes to the other buffer while this one is used (its
+    // last readers passed the barrier that ended the previous iteration)
+    if (tc + 1 < g.ngroup)
+      stage_weights<CIN, BLOCK>(wl2[(tc + 1) & 1], wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN),
+                                threadIdx.x);
+    const float *wl = wl2[tc & 1];
     const int causal_base = (tc + slack) * group_in;
     float acc[PP][GO];
 #pragma unroll
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
         y[obase[j] + pout] = v;
       }
     }
+    __syncthreads();
   }
 }
 
