@@ -189,15 +189,21 @@ __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict
   for (int i = tid; i < N4; i += BLOCK) dst[i] = src[i];
 }
 
-// Step form: grid = 3 weight sets x planes of the step's window x `split`.  All
-// positions of a plane share the output group, so a wave loads its share of the
-// (set, group) weight slab ONCE into registers -- 17 taps x 3 rows per lane for 42
-// input channels, causally masked taps as zeros -- together with the window
-// offsets of those taps, and then walks the plane's (image, position) list with
-// stride split*waves: per position 17 gathers from one scalar base, 51 fmaf, the
-// butterfly, the epilogue.  No LDS, no barrier: the waves are independent.
-template <int CIN, int ITER, int BLOCK>
-__global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
+// Step form: grid = 3 weight sets x planes of the step's window x images x `split`.
+// All positions of a plane share the output group, so the (set, group) weight slab
+// is fetched ONCE per workgroup, causally masked taps as zeros, together with the
+// window offsets of the taps; the waves then walk the plane's position list with
+// stride split*waves: per position 17 gathers from one scalar base (42 input
+// channels), 51 fmaf, the butterfly, the epilogue.  The launch is latency-bound
+// (a wave's positions form a chain of memory round trips), so what matters is how
+// many waves are resident:
+//   WLDS  the slab lives in LDS (float4 per tap + a dword offset array, 21 KB per
+//         workgroup) and a lane keeps only its 17 window values: ~64 registers,
+//         8 waves per SIMD;
+//   else  each lane holds its taps' weights and offsets in registers (5 per tap):
+//         for wide layers whose slab does not fit LDS several times per CU.
+template <int CIN, int ITER, int BLOCK, bool WLDS>
+__global__ __launch_bounds__(BLOCK, WLDS ? 8 : waves_per_eu(ITER)) void ee_conv_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
     float *__restrict__ y, int cout, int constrain, int pad_out, int first_plane, int nplane, int split,
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
   const int cnt = g.plane_start[plane + 1] - lo;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  if (part * kWaves + wave >= cnt) return;
+  if (!WLDS && part * kWaves + wave >= cnt) return;
   const int tc = psum - plane;
   const int group_in = CIN / g.ngroup;
   const int h = g.h, w = g.w;
@@ -232,9 +238,23 @@ __global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
   // gets zero weights: fmaf(x, 0, acc) leaves acc unchanged (x is finite).
   const int causal_base = (tc + slack) * group_in;
   const float4 *slab = reinterpret_cast<const float4 *>(wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN));
-  unsigned off[ITER];  // byte offsets: unsigned 32-bit, so the gathers are "scalar base + lane offset" loads
-  float w0[ITER], w1[ITER], w2[ITER];
-  {
+  constexpr int SLOTS = WLDS ? ITER * kWave : 1;
+  __shared__ __attribute__((aligned(16))) float4 lw[SLOTS];
+  __shared__ unsigned lo4[SLOTS];
+  unsigned off[WLDS ? 1 : ITER];  // byte offsets: unsigned 32-bit, so the gathers are "scalar base + lane offset" loads
+  float w0[WLDS ? 1 : ITER], w1[WLDS ? 1 : ITER], w2[WLDS ? 1 : ITER];
+  if (WLDS) {
+    if (part * kWaves >= cnt) return;  // uniform for the workgroup
+    for (int kk = threadIdx.x; kk < SLOTS; kk += BLOCK) {
+      const int tap = kk / CIN, ci = kk - tap * CIN;
+      const int kh = tap / K, kw = tap - kh * K;
+      const bool ok = (kk < RED) && ((2 * HALF - kh - kw) * group_in - ci + causal_base > 0);
+      lw[kk] = ok ? slab[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
+      lo4[kk] = ok ? 4u * (unsigned)((kh * win + kw) * CIN + ci) : 0u;
+    }
+    __syncthreads();
+    if (part * kWaves + wave >= cnt) return;
+  } else {
     TapWalk<CIN> tw(lane);
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
     for (int it = 0; it < ITER; it++) {
       // (opaque to the optimiser: a zero-extension hoisted out of the loop would
       // turn every gather into a 64-bit VALU add + a 2-register address)
-      unsigned o = off[it];
+      unsigned o = WLDS ? lo4[lane + it * kWave] : off[it];
       asm volatile("" : "+v"(o));
       xv[it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
     }
@@ -288,9 +308,16 @@ __global__ __launch_bounds__(BLOCK, waves_per_eu(ITER)) void ee_conv_kernel(
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
-      a0 = fmaf(xv[it], w0[it], a0);
-      a1 = fmaf(xv[it], w1[it], a1);
-      a2 = fmaf(xv[it], w2[it], a2);
+      if (WLDS) {
+        const float4 wv = lw[lane + it * kWave];
+        a0 = fmaf(xv[it], wv.x, a0);
+        a1 = fmaf(xv[it], wv.y, a1);
+        a2 = fmaf(xv[it], wv.z, a2);
+      } else {
+        a0 = fmaf(xv[it], w0[it], a0);
+        a1 = fmaf(xv[it], w1[it], a1);
+        a2 = fmaf(xv[it], w2[it], a2);
+      }
     }
     a0 = butterfly_sum(a0);
     a1 = butterfly_sum(a1);
@@ -572,10 +599,12 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   int split = (longest_plane + kWaves * kPosPerWave - 1) / (kWaves * kPosPerWave);
   if (split < 1) split = 1;
   const long long grid = (long long)3 * nplane * g->nimg * split;
+  // weights in LDS while the slab fits a CU several times (measured at 42 input channels:
+  // decode of 4 lock-step frames 0.25 -> 0.20 s against the register form)
 #define EE_LAUNCH(CIN, ITER)                                                                                  \
-  hipLaunchKernelGGL((ee_conv_kernel<CIN, ITER, kConvBlock>), dim3((unsigned)grid), dim3(kConvBlock), 0,      \
-                     as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
-                     pad_out, first_plane, nplane, split, psum)
+  hipLaunchKernelGGL((ee_conv_kernel<CIN, ITER, kConvBlock, (ITER <= 20)>), dim3((unsigned)grid),             \
+                     dim3(kConvBlock), 0, as_stream(stream), *g, x, shared_input, packed_w, bias, slope,      \
+                     residual, y, cout, constrain, pad_out, first_plane, nplane, split, psum)
   if (cin == 14) {
     EE_LAUNCH(14, 6);
   } else if (cin == 42) {

@@ -10,7 +10,7 @@ g = torch.Generator().manual_seed(7)
 sd = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in enc.ent.state_dict().items()}
 enc.ent.load_state_dict(sd); dec.ent.load_state_dict(sd); dec.quant.weight.data.copy_(enc.quant.weight.data)
 eng = CodecEngine(56, 0, enc, dec)
-sizes = [(512, 1024, 1), (2048, 4096, 1)] + ([(2048, 4096, 2), (2048, 4096, 4)] if "--batch" in sys.argv else [])
+sizes = [(512, 1024, 1), (2048, 4096, 1)] + ([(2048, 4096, 2), (2048, 4096, 4)] if "--batch" in sys.argv else []) + ([(2048, 4096, 8)] if "--batch8" in sys.argv else [])
 for (H, W, N) in sizes:
     x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
     for rep in range(2):
