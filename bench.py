@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed passes before the warm-up so that the caching allocator reaches steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="512x1024", help="HxW of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="256x512", help="HxW of the CPU baseline sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
