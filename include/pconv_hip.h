@@ -129,6 +129,15 @@ int pconv_pseudo_pad(const float *in, float *out, const int32_t *widths,
                      const float *wgt, int tn, int c, int h, int w, int pad, int npart,
                      void *stream);
 
+/* The same when the producer has already written the tensor into the interior of
+ * a padded buffer (pconv_conv2d / pconv_gdn with an output view): buf (tn, c,
+ * h + 2*store, w + 2*store) holds the data at offset (store, store); only the ring
+ * of the pad-p view (p <= store, origin (store - p, store - p)) is computed, in
+ * place.  Tables as for pconv_pseudo_pad with the same pad. */
+int pconv_pseudo_pad_ring(float *buf, const int32_t *widths, const int32_t *src_tile,
+                          const int32_t *src_row, const int32_t *col, const float *wgt, int tn,
+                          int c, int h, int w, int pad, int store, int npart, void *stream);
+
 /* PseudoFillOp.forward, in place  (pseudo_fill_cuda.cu:28-62) */
 int pconv_pseudo_fill(float *data, const int32_t *widths, int tn, int c, int h, int w,
                       int npart, int pad, int trim, float fvalue, void *stream);
@@ -185,14 +194,19 @@ int pconv_gmm_loss(const float *weight, const float *delta, const float *mean,
  * * gate[.], + residual[.] (both shaped like out, may be NULL: the attention
  * product and the residual sum that follow the convolution in
  * model_zoo_v2.py:53,76,93,114,175) and, with trim != 0, zero from col_limit on
- * (the PseudoFill that ends every block). */
+ * (the PseudoFill that ends every block).
+ * views (may be NULL = all dense NCHW): 12 element strides, (tile, channel, row)
+ * for in, out, residual, gate in this order; columns are always contiguous.
+ * Lets a convolution write the interior of a padded buffer (whose ring
+ * pconv_pseudo_pad_ring then fills) and read such interiors. */
 int pconv_conv_packed_size(int cout, int cin, int k, int *cout_pad, int *red_pad);
 int pconv_conv_pack_weight(const float *w, float *packed, int cout, int cin, int k,
                            void *stream);
 int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
                  int tn, int cin, int h, int w, int cout, int k, int stride, int act,
                  const float *slope, const int32_t *col_limit, int npart,
-                 const float *residual, const float *gate, int trim, void *stream);
+                 const float *residual, const float *gate, int trim, const long long *views,
+                 void *stream);
 
 /* PseudoGDNV2.forward (PseudoContextV2.py:133-216) in one launch on the same
  * kernel: out = in / sqrt(beta + gamma * in^2) over channels (inverse: in * sqrt),
@@ -202,6 +216,7 @@ int pconv_conv2d(const float *in, const float *packed_w, const float *bias, floa
 int pconv_gdn(const float *in, const float *packed_gamma, const float *beta, float *out,
               int tn, int ch, int h, int w, int inverse, const int32_t *col_limit, int npart,
               const float *residual /* added inside the valid columns, may be NULL */,
+              const long long *views /* 9 strides: in, out, residual; may be NULL */,
               void *stream);
 
 /* ------------------------------------------------------------------------

@@ -410,6 +410,22 @@ class PseudoPadOp(_Op):
              c, h, w, p, self.npart_, _stream(x.device))
         return [out]
 
+    def forward_ring(self, x):
+        """x is the interior view of a padded buffer (`x._pconv_ring = (buffer, store)`, set by
+        tile_conv2d / tile_gdn with ring > 0): fill the ring of this op's pad in place and
+        return the padded view -- no copy of the tensor."""
+        buf, store = x._pconv_ring
+        tn, c, h, w = x.shape
+        p = self.pad_
+        if p <= 0 or p > store or tuple(buf.shape) != (tn, c, h + 2 * store, w + 2 * store) or not buf.is_contiguous():
+            return self.forward(x.contiguous())[0]
+        wd = self.ctx_.widths(h, w, x)
+        st, sr, col, wgt = self.ctx_.pad_tables(h, w, p, x)
+        call("pconv_pseudo_pad_ring", _ptr(buf), _ptr(wd), _ptr(st), _ptr(sr), _ptr(col), _ptr(wgt), tn, c, h, w, p,
+             store, self.npart_, _stream(x.device))
+        d = store - p
+        return buf if d == 0 else buf[:, :, d:-d, d:-d]
+
     def backward(self, grad):
         raise NotImplementedError("PseudoPadOp.backward: training path is out of scope (SURVEY 2.1)")
 
@@ -885,21 +901,53 @@ def _like_output(t, out, what):
     if tuple(t.shape) != tuple(out.shape) or t.device != out.device or t.dtype != torch.float32:
         raise PconvError("%s: expected a float32 tensor shaped like the output %s, got %s"
                          % (what, tuple(out.shape), tuple(t.shape)))
-    return t if t.is_contiguous() else t.contiguous()
+    return t if t.stride(3) == 1 else t.contiguous()
 
 
-def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=None):
+def _require_rows(x, what):
+    """GPU float32 4-D tensor whose columns are contiguous (dense, or the interior view
+    of a padded buffer)"""
+    if not x.is_cuda:
+        raise PconvError("%s: expected a GPU tensor (this build has no CPU path), got %s" % (what, x.device))
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise PconvError("%s: only 4-D float32 is supported, got %s %s" % (what, x.dtype, tuple(x.shape)))
+    return x if x.stride(3) == 1 else x.contiguous()
+
+
+def _views(*tensors):
+    """(tile, channel, row) element strides of each tensor for the C ABI; a missing tensor
+    gets zeros (never dereferenced)"""
+    flat = []
+    for t in tensors:
+        flat += [0, 0, 0] if t is None else [t.stride(0), t.stride(1), t.stride(2)]
+    return (ctypes.c_longlong * len(flat))(*flat)
+
+
+def _ring_output(shape, ring, like):
+    """output tensor; with ring > 0 the interior view of a fresh padded buffer, tagged so
+    that PseudoPadOp.forward_ring finds the buffer"""
+    tn, c, h, w = shape
+    if ring <= 0:
+        return torch.empty(shape, dtype=torch.float32, device=like.device)
+    buf = torch.empty((tn, c, h + 2 * ring, w + 2 * ring), dtype=torch.float32, device=like.device)
+    out = buf[:, :, ring:-ring, ring:-ring]
+    out._pconv_ring = (buf, ring)
+    return out
+
+
+def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=None, ring=0):
     """PseudoGDNV2.forward in one launch: x / sqrt(beta + gamma x^2) (inverse: x * sqrt)
     (+ residual), zeros from each tile's col_limit on.  gamma (ch, ch), beta (ch):
-    effective values."""
-    _require_gpu(x, "tile_gdn")
+    effective values.  ring: see tile_conv2d."""
+    x = _require_rows(x, "tile_gdn")
     tn, ch, h, w = x.shape
     stream = _stream(x.device)
     packed = packed_conv_weight(owner, gamma.view(ch, ch, 1, 1), stream)
-    out = torch.empty_like(x)
+    out = _ring_output((tn, ch, h, w), ring, x)
     residual = _like_output(residual, out, "tile_gdn: residual")
+    views = _views(x, out, residual)
     call("pconv_gdn", _ptr(x), _ptr(packed), _ptr(beta.detach().contiguous()), _ptr(out), tn, ch, h, w,
-         1 if inverse else 0, _ptr(col_limit), int(npart), _ptr(residual), stream)
+         1 if inverse else 0, _ptr(col_limit), int(npart), _ptr(residual), ctypes.addressof(views), stream)
     return out
 
 
@@ -907,11 +955,14 @@ FUSED_EPILOGUE = True  # tile_conv2d takes sigmoid / gate / residual / trim
 
 
 def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0, sigmoid=False, gate=None,
-                residual=None, trim=False):
+                residual=None, trim=False, ring=0):
     """y = conv2d(x, weight, bias, stride), no padding, on the fp32 matrix cores, then in
     the same launch PReLU(slope) or sigmoid, * gate, + residual, and (trim) zeros from
-    each tile's col_limit on.  x (tn, cin, h, w) -> (tn, cout, ho, wo)."""
-    _require_gpu(x, "tile_conv2d")
+    each tile's col_limit on.  x (tn, cin, h, w) -> (tn, cout, ho, wo).  x, gate and
+    residual may be interior views of padded buffers.  ring > 0: the result is written
+    into the interior of a buffer padded by `ring` (returned as that view), so that a
+    following PseudoPad only has to fill the ring."""
+    x = _require_rows(x, "tile_conv2d")
     tn, cin, h, w = x.shape
     cout, cin_w, k, k2 = weight.shape
     if cin != cin_w or k != k2:
@@ -919,7 +970,7 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     stream = _stream(x.device)
     packed = packed_conv_weight(owner, weight, stream)
     ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
-    out = torch.empty((tn, cout, ho, wo), dtype=torch.float32, device=x.device)
+    out = _ring_output((tn, cout, ho, wo), ring, x)
     probe = conv_probe
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -928,10 +979,11 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
         raise PconvError("tile_conv2d: PReLU and sigmoid are exclusive")
     gate = _like_output(gate, out, "tile_conv2d: gate")
     residual = _like_output(residual, out, "tile_conv2d: residual")
+    views = _views(x, out, residual, gate)
     call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
          tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
          _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
-         _ptr(residual), _ptr(gate), 1 if trim else 0, stream)
+         _ptr(residual), _ptr(gate), 1 if trim else 0, ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         tile = "192" if cout > 96 else ("96" if cout > 32 else "32")

@@ -131,6 +131,12 @@ class PseudoPadV2(BaseOpModule):
         self.op = _per_gpu(self, lambda g: backend.ops().PseudoPadOp(pad, npart, ctx.get_addr(g), g, time_it))
 
     def forward(self, x):
+        op = self.native(x)
+        if getattr(x, "_pconv_ring", None) is not None and hasattr(op, "forward_ring") \
+                and not torch.is_grad_enabled():
+            # x already lives inside a padded buffer (its producer wrote it there):
+            # only the ring is computed, no copy
+            return op.forward_ring(x)
         return native_call(self, 'forward', (x,))
 
 
@@ -201,7 +207,7 @@ class PseudoGDNV2(nn.Module):
             self._effective = (key, gamma.contiguous(), beta.contiguous())
         return self._effective[1], self._effective[2]
 
-    def forward(self, inputs, residual=None, trim=None):
+    def forward(self, inputs, residual=None, trim=None, ring=0):
         """reference signature: forward(inputs).  residual / trim (a PseudoFill module):
         the `trim(residual + gdn(inputs))` that ends ResidualBlockDown / ResidualBlockUp,
         evaluated in the same launch when the backend can."""
@@ -212,7 +218,7 @@ class PseudoGDNV2(nn.Module):
             gamma, beta = self.effective()
             ctx_op = self.ctx.native(inputs)
             limit, npart = ops.conv_col_limit(ctx_op, inputs.shape[2], inputs.shape[3], 0, inputs)
-            return ops.tile_gdn(self, inputs.contiguous(), gamma, beta, self.inverse, limit, npart, residual)
+            return ops.tile_gdn(self, inputs, gamma, beta, self.inverse, limit, npart, residual, ring)
         out = self._formula(inputs)
         if residual is not None:
             out = residual + out

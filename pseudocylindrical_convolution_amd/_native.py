@@ -32,6 +32,7 @@ _HIP_SIGNATURES = {
     "pconv_sphere_slice": [P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_sphere_uslice": [P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_pseudo_pad": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "pconv_pseudo_pad_ring": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "pconv_pseudo_fill": [P, P, I, I, I, I, I, I, I, F, P],
     "pconv_dtow": [P, P, I, I, I, I, I, I, P],
     "pconv_quant": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
@@ -42,8 +43,8 @@ _HIP_SIGNATURES = {
     "pconv_gmm_loss": [P, P, P, P, P, P, P, P, P, I, I, P],
     "pconv_conv_packed_size": [I, I, I, P, P],
     "pconv_conv_pack_weight": [P, P, I, I, I, P],
-    "pconv_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, P, P, I, P],
-    "pconv_gdn": [P, P, P, P, I, I, I, I, I, P, I, P, P],
+    "pconv_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, P, P, I, P, P],
+    "pconv_gdn": [P, P, P, P, I, I, I, I, I, P, I, P, P, P],
     # entropy wavefront
     "pconv_dinput2": [P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "pconv_ctx_pad_run2": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],

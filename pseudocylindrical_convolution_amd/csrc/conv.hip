@@ -70,16 +70,25 @@ struct ConvCfg {
 // gate and residual have the output's shape.  This replaces up to four
 // element-wise passes over the activation that follow the convolution in the
 // reference's graph (sigmoid, mul, add, fill).
+// element strides of a (tile, channel, row, column) tensor whose columns are contiguous:
+// lets a convolution read from / write into the interior of a padded buffer
+struct ConvView {
+  long long ts, cs;
+  int rs;
+};
+
 struct ConvEpilogue {
   const float *bias, *slope, *residual, *gate;
   const int32_t *col_limit;  // per latitude tile: first dead output column (may be null)
   int npart, act, trim;
+  ConvView vres, vgate;
 };
 
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
-    int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, ConvEpilogue ep) {
+    int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, ConvView vin,
+    ConvView vout, ConvEpilogue ep) {
   const float *__restrict__ bias = ep.bias;
   const float *__restrict__ slope = ep.slope;
   const int32_t *__restrict__ col_limit = ep.col_limit;
@@ -112,19 +121,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
 
-  float *outp = out + (size_t)t * cout * ho * wo;
+  float *outp = out + (size_t)t * vout.ts;
 
   if (col_limit && c0 >= col_limit[t % npart]) {
     // tile lies entirely in the dead columns of this latitude band: zeros
     for (int e = tid; e < C::BM * kTileRows * kTileCols; e += kThreads) {
       const int col = e % kTileCols, row = (e / kTileCols) % kTileRows, co = e / (kTileCols * kTileRows);
       if (cout0 + co < cout && r0 + row < ho && c0 + col < wo)
-        outp[((size_t)(cout0 + co) * ho + r0 + row) * wo + c0 + col] = 0.f;
+        outp[(size_t)(cout0 + co) * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
     }
     return;
   }
 
-  const float *inp = in + (size_t)t * cin * h * w;
+  const float *inp = in + (size_t)t * vin.ts;
   const int nchunk = (cin + KC - 1) / KC;
 
   f32x16 acc[MT][NT];
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     int ic = c0 * S + pc * P::PS;
     ir = ir < h ? ir : h - 1;
     ic = ic < w ? ic : w - 1;
-    xoffs[j] = (unsigned)((ci * h + ir) * w + ic);
+    xoffs[j] = (unsigned)(ci * vin.cs + (long long)ir * vin.rs + ic);
   }
 #pragma unroll
   for (int j = 0; j < C::WLD; j++) {
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     woffs[j] = (unsigned)(kk * cout_pad + co);
   }
   const int tail = cin % KC;  // channels of a ragged last chunk (0: none)
-  const size_t xstep = (size_t)KC * h * w, wstep = (size_t)C::KK * cout_pad;
+  const size_t xstep = (size_t)KC * vin.cs, wstep = (size_t)C::KK * cout_pad;
 
   typedef __attribute__((address_space(3))) void lds_ptr_t;
   typedef const __attribute__((address_space(1))) void glb_ptr_t;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
           // channels past cin: read the last real one instead -- their rows of the
           // packed weight are zero, so the product adds +0 to the chain
           const int ci = e / (P::PC * P::PR);
-          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * h * w);
+          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs);
         }
         __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(xs + j * kThreads + wave * 64),
                                          4, 0, 0);
@@ -261,9 +270,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
   }
 
   const int trim_at = ((ep.trim || act == 2 || act == 3) && col_limit) ? col_limit[t % npart] : wo;
-  const size_t tile_out = (size_t)t * cout * ho * wo;
-  const float *resp = ep.residual ? ep.residual + tile_out : nullptr;
-  const float *gatep = ep.gate ? ep.gate + tile_out : nullptr;
+  const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+  const float *gatep = ep.gate ? ep.gate + (size_t)t * ep.vgate.ts : nullptr;
   // epilogue (see ConvEpilogue).  reg r of a 32x32 tile: cout row
   // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
 #pragma unroll
@@ -279,20 +287,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
         const int seg = wn * NT + n;
         const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
         if (orow < ho && ocol < wo) {
-          const size_t oi = ((size_t)co * ho + orow) * wo + ocol;
+          const size_t oi = (size_t)co * vout.cs + (size_t)orow * vout.rs + ocol;
           float v = acc[m][n][r] + bco;
           if (act == 1) {
             if (v < 0) v = v * sl;
           } else if (act == 2 || act == 3) {
             // 1x1, stride 1: input and output share their geometry
-            const float xv = inp[oi];
+            const float xv = inp[(size_t)co * vin.cs + (size_t)orow * vin.rs + ocol];
             const float nrm = sqrtf(v);
             v = act == 2 ? xv / nrm : xv * nrm;
           } else if (act == 4) {
             v = 1.f / (1.f + expf(-v));
           }
-          if (gatep) v = gatep[oi] * v;
-          if (resp) v = resp[oi] + v;
+          if (gatep) v = gatep[(size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + ocol] * v;
+          if (resp) v = resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol] + v;
           if (ocol >= trim_at) v = 0.f;
           outp[oi] = v;
         }
@@ -312,7 +320,8 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
 
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ = false>
 int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout,
-                int cout_pad, int ho, int wo, const ConvEpilogue &ep, hipStream_t stream) {
+                int cout_pad, int ho, int wo, const ConvView &vin, const ConvView &vout, const ConvEpilogue &ep,
+                hipStream_t stream) {
   using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
   constexpr int kThreads = C::THREADS;
   constexpr int kTileRows = C::ROWS;
@@ -337,11 +346,23 @@ int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, i
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, out, cin, h, w, cout,
-                     cout_pad, ho, wo, tiles_r, tiles_c, cblocks, ep);
+                     cout_pad, ho, wo, tiles_r, tiles_c, cblocks, vin, vout, ep);
   return PCONV_OK;
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+inline ConvView dense_view(int c, int h, int w) { return {(long long)c * h * w, (long long)h * w, w}; }
+
+// views[3*i .. 3*i+2] = (tile, channel, row) strides of tensor i, or a dense view when views is null
+inline ConvView view_at(const long long *views, int i, int c, int h, int w) {
+  if (!views) return dense_view(c, h, w);
+  return {views[3 * i], views[3 * i + 1], (int)views[3 * i + 2]};
+}
+
+inline bool view_ok(const ConvView &v, int c, int h, int w) {
+  return v.rs >= w && v.cs >= (long long)(h - 1) * v.rs + w && v.ts >= (long long)(c - 1) * v.cs + (long long)(h - 1) * v.rs + w;
+}
 
 }  // namespace
 
@@ -369,7 +390,8 @@ extern "C" int pconv_conv_pack_weight(const float *w, float *packed, int cout, i
 extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
                             int tn, int cin, int h, int w, int cout, int k, int stride, int act,
                             const float *slope, const int32_t *col_limit, int npart,
-                            const float *residual, const float *gate, int trim, void *stream) {
+                            const float *residual, const float *gate, int trim, const long long *views,
+                            void *stream) {
   PCONV_REQUIRE(in && packed_w && out, "conv2d: null pointer");
   PCONV_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv2d: k=%d stride=%d unsupported",
                 k, stride);
@@ -382,9 +404,16 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
   int cp, rp;
   pconv_conv_packed_size(cout, cin, k, &cp, &rp);
   hipStream_t s = as_stream(stream);
-  const ConvEpilogue ep = {bias, slope, residual, gate, col_limit, npart, act, trim};
+  const ConvView vin = view_at(views, 0, cin, h, w), vout = view_at(views, 1, cout, ho, wo);
+  const ConvEpilogue ep = {bias,  slope, residual, gate, col_limit, npart, act, trim,
+                           view_at(views, 2, cout, ho, wo), view_at(views, 3, cout, ho, wo)};
+  PCONV_REQUIRE(view_ok(vin, cin, h, w) && view_ok(vout, cout, ho, wo) &&
+                    (!residual || view_ok(ep.vres, cout, ho, wo)) && (!gate || view_ok(ep.vgate, cout, ho, wo)),
+                "conv2d: strides overlap");
+  PCONV_REQUIRE((long long)(16 - 1) * vin.cs + (long long)(h - 1) * vin.rs + w < (1LL << 32),
+                "conv2d: input channel stride too large for 32-bit chunk offsets");
   int rc;
-#define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, ep, s
+#define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, vin, vout, ep, s
   // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):
   //   cout > 96 : 192 couts x (2 rows x 64 px), 4 waves of 96 x 64
   //   cout > 32 :  96 couts x (4 rows x 64 px), 8 waves of 96 x 32
@@ -419,21 +448,26 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
 // -- eight passes over the activation.
 extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float *beta, float *out, int tn,
                          int ch, int h, int w, int inverse, const int32_t *col_limit, int npart,
-                         const float *residual, void *stream) {
+                         const float *residual, const long long *views, void *stream) {
   PCONV_REQUIRE(in && packed_gamma && beta && out && in != out && residual != out, "gdn: bad pointer");
   PCONV_REQUIRE(tn > 0 && ch > 0 && h > 0 && w > 0, "gdn: bad shape");
   PCONV_REQUIRE(!col_limit || npart > 0, "gdn: col_limit needs npart");
   int cp, rp;
   pconv_conv_packed_size(ch, ch, 1, &cp, &rp);
   hipStream_t s = as_stream(stream);
-  const ConvEpilogue ep = {beta, nullptr, residual, nullptr, col_limit, npart, inverse ? 3 : 2, 1};
+  // views: in, out, residual
+  const ConvView vin = view_at(views, 0, ch, h, w), vout = view_at(views, 1, ch, h, w);
+  const ConvEpilogue ep = {beta, nullptr, residual, nullptr, col_limit, npart, inverse ? 3 : 2, 1,
+                           view_at(views, 2, ch, h, w), dense_view(ch, h, w)};
+  PCONV_REQUIRE(view_ok(vin, ch, h, w) && view_ok(vout, ch, h, w) && (!residual || view_ok(ep.vres, ch, h, w)),
+                "gdn: strides overlap");
   int rc;
   if (ch > 96)
-    rc = launch_conv<3, 2, 2, 2, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, ep, s);
+    rc = launch_conv<3, 2, 2, 2, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)
-    rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, ep, s);
+    rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else
-    rc = launch_conv<1, 1, 1, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, ep, s);
+    rc = launch_conv<1, 1, 1, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   if (rc != PCONV_OK) return rc;
   PCONV_LAUNCH_CHECK("gdn");
   return PCONV_OK;

@@ -66,6 +66,82 @@ __global__ __launch_bounds__(kBlock) void pseudo_pad_kernel(
   }
 }
 
+// PseudoPad when the tensor already lives in the interior of a padded buffer
+// (written there by the convolution that produced it): only the ring is computed.
+// buf: (tn, c, h + 2*store, w + 2*store), the data at offset (store, store); the
+// padded tensor of pad p <= store is the sub-view starting at (store - p, store - p).
+// Per interior row 3p + (store - p) elements: left wrap, right wrap, the ring
+// columns to the right of the interior (zero unless the wrap reaches them) and
+// the interior columns a wider pad of the same buffer could have written before;
+// per halo row the whole row, as pseudo_pad_kernel defines it.  Interior columns
+// past the wrap are the producer's (it trims them to zero).
+__global__ __launch_bounds__(kBlock) void pseudo_pad_ring_kernel(
+    float *__restrict__ buf, const int32_t *__restrict__ widths, const int32_t *__restrict__ src_tile,
+    const int32_t *__restrict__ src_row, const int32_t *__restrict__ col, const float *__restrict__ wgt,
+    int c, int h, int w, int pad, int store, int npart, long long n_side, long long n_halo) {
+  const int sh = h + 2 * store, sw = w + 2 * store;  // storage extent
+  const int ow = w + 2 * pad, shift = store - pad;   // view extent / view -> storage offset
+  const int per_row = 3 * pad + shift;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_side + n_halo;
+       i += (long long)gridDim.x * kBlock) {
+    if (i < n_side) {
+      const int k = (int)(i % per_row);
+      const long long row = i / per_row;  // (tile-batch*c + channel)*h + r
+      const int r = (int)(row % h);
+      const long long tc = row / h;
+      const int tg = (int)((tc / c) % npart);
+      const int valid = widths[tg];
+      float *line = buf + ((size_t)tc * sh + store + r) * sw;  // storage row of data row r
+      const float *data = line + store;
+      int j;  // view column
+      float v = 0.f;
+      if (k < pad) {
+        j = k;
+        v = data[valid - pad + k];
+      } else if (k < 2 * pad) {
+        j = pad + valid + (k - pad);
+        v = data[k - pad];
+      } else if (k < 3 * pad) {
+        j = pad + w + (k - 2 * pad);
+        if (j < valid + 2 * pad) continue;  // the wrap wrote it
+      } else {
+        j = valid + 2 * pad + (k - 3 * pad);
+        if (j >= pad + w) continue;  // outside the interior: handled as ring
+      }
+      line[j + shift] = v;
+    } else {
+      const long long e0 = i - n_side;
+      const int j = (int)(e0 % ow);
+      const long long hr = e0 / ow;  // (tile-batch*c + channel)*2*pad + halo row index
+      const int q = (int)(hr % (2 * pad));
+      const long long tc = hr / (2 * pad);
+      const int pc = (int)(tc % c);
+      const long long tb = tc / c;
+      const int tg = (int)(tb % npart);
+      const long long img = tb / npart;
+      const int side = q >= pad, rr = side ? q - pad : q;
+      const int valid = widths[tg];
+      const int rview = side ? pad + h + rr : rr;
+      float v = 0.f;
+      if (j < valid + 2 * pad) {
+        int x = j - pad;
+        x += (x < 0) ? valid : 0;
+        x -= (j >= valid + pad) ? valid : 0;
+        const int e = (tg * 2 + side) * pad + rr;
+        const int st = src_tile[e];
+        const int svalid = widths[st];
+        const float *src = buf + ((((size_t)(img * npart + st) * c + pc) * sh) + store + src_row[e]) * sw + store;
+        const int qc = col[(size_t)e * w + x];
+        const float t = wgt[(size_t)e * w + x];
+        int q1 = qc + 1;
+        q1 = (q1 >= svalid) ? q1 - svalid : q1;
+        v = src[qc] * t + src[q1] * (1 - t);
+      }
+      buf[((size_t)tc * sh + rview + shift) * sw + j + shift] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void pseudo_fill_kernel(float *__restrict__ data,
                                                              const int32_t *__restrict__ widths,
                                                              int c, int h, int w, int npart,
@@ -182,6 +258,20 @@ extern "C" int pconv_pseudo_pad(const float *in, float *out, const int32_t *widt
   hipLaunchKernelGGL(pseudo_pad_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), in, out,
                      widths, src_tile, src_row, col, wgt, c, h, w, pad, npart, nrows);
   PCONV_LAUNCH_CHECK("pseudo_pad");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_pseudo_pad_ring(float *buf, const int32_t *widths, const int32_t *src_tile,
+                                     const int32_t *src_row, const int32_t *col, const float *wgt, int tn,
+                                     int c, int h, int w, int pad, int store, int npart, void *stream) {
+  PCONV_REQUIRE(buf && widths && src_tile && src_row && col && wgt, "pseudo_pad_ring: null pointer");
+  PCONV_REQUIRE(tn > 0 && tn % npart == 0 && c > 0 && h > 0 && w > 0 && pad > 0 && pad <= store,
+                "pseudo_pad_ring: bad shape tn=%d c=%d h=%d w=%d pad=%d store=%d", tn, c, h, w, pad, store);
+  const long long n_side = (long long)tn * c * h * (3 * pad + store - pad);
+  const long long n_halo = (long long)tn * c * 2 * pad * (w + 2 * pad);
+  hipLaunchKernelGGL(pseudo_pad_ring_kernel, dim3(pconv_grid(n_side + n_halo)), dim3(kBlock), 0, as_stream(stream),
+                     buf, widths, src_tile, src_row, col, wgt, c, h, w, pad, store, npart, n_side, n_halo);
+  PCONV_LAUNCH_CHECK("pseudo_pad_ring");
   return PCONV_OK;
 }
 

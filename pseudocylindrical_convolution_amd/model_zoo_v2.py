@@ -52,6 +52,8 @@ class TileConv2d(nn.Conv2d):
       gate              y = gate * y          (attention: trunk * sigmoid(conv))
       residual          y = residual + y      (x + f(x) of the residual blocks)
       trim              the PseudoFill module that ends the block
+      ring              write the result into the interior of a buffer padded by `ring`,
+                        so that the PseudoPad of the consumer only fills the ring (no copy)
     `live=(ctx, base)` tells the kernel which output columns can ever be read: tile t
     only needs columns < widths_t(base) + (wo - base), base = tile width of the
     scale the output lives in; 64-column blocks beyond that are written as zeros
@@ -60,7 +62,7 @@ class TileConv2d(nn.Conv2d):
     PCONV_TILE_CONV=vendor for A/B timing -- never used for parity claims) the same
     operations run one by one, in the same order."""
 
-    def _native(self, x, prelu=None, live=None, sigmoid=False, gate=None, residual=None, trim=None):
+    def _native(self, x, prelu=None, live=None, sigmoid=False, gate=None, residual=None, trim=None, ring=0):
         ops = backend.ops()
         slope = prelu.weight if prelu is not None else None
         vendor = os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d")
@@ -75,7 +77,8 @@ class TileConv2d(nn.Conv2d):
                 raise ValueError("trim on an output that still carries halo columns")
         if fused and (trim is None or limit is not None):
             return ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope, limit, npart,
-                                   sigmoid=sigmoid, gate=gate, residual=residual, trim=trim is not None)
+                                   sigmoid=sigmoid, gate=gate, residual=residual, trim=trim is not None,
+                                   ring=ring)
         if vendor:
             y = nn.functional.conv2d(x, self.weight, self.bias, self.stride)
             y = nn.functional.prelu(y, slope) if slope is not None else y
@@ -94,6 +97,11 @@ class TileConv2d(nn.Conv2d):
 
     def fuse(self, x, prelu, live=None, **epilogue):
         return self._native(x, prelu, live, **epilogue)
+
+
+# block outputs live inside buffers padded by the largest pad of the graph, so that the
+# consumer's PseudoPad fills a ring instead of copying the tensor (PCONV_PAD_RING=0: A/B timing)
+RING = 2 if os.environ.get("PCONV_PAD_RING", "1") == "1" else 0
 
 
 def _conv(cin, cout, k, stride=1):
@@ -119,7 +127,7 @@ class ResidualBlock(nn.Module):
         live = (self.ctx, x.shape[3])
         y = self.conv1.fuse(self.pad(x), self.relu1, live)
         y = self.conv2.fuse(y, self.relu2, live)
-        return self.conv3(y, live, residual=x, trim=self.trim)
+        return self.conv3(y, live, residual=x, trim=self.trim, ring=RING)
 
 
 class AttentionBlock(nn.Module):
@@ -140,7 +148,7 @@ class AttentionBlock(nn.Module):
         for m in self.attention[:3]:
             a = m(a)
         return self.attention[3](a, (self.ctx, x.shape[3]), sigmoid=True, gate=self.trunk(x), residual=x,
-                                 trim=self.trim)
+                                 trim=self.trim, ring=RING)
 
 
 class ResidualBlockV2(nn.Module):
@@ -159,7 +167,7 @@ class ResidualBlockV2(nn.Module):
     def forward(self, x):
         live = (self.ctx, x.shape[3])
         y = self.conv1.fuse(self.pad(x), self.relu1, live)
-        return self.conv2.fuse(y, self.relu2, live, residual=x, trim=self.trim)
+        return self.conv2.fuse(y, self.relu2, live, residual=x, trim=self.trim, ring=RING)
 
 
 class ResidualBlockDown(nn.Module):
@@ -180,8 +188,8 @@ class ResidualBlockDown(nn.Module):
     def forward(self, x):
         live = (self.ctx, x.shape[3] // 2)
         t = self.short_cut(x, live)
-        y = self.conv1.fuse(self.pad1(x), self.relu1, live)
-        return self.relu2(self.conv2(self.pad2(y), live), residual=t, trim=self.trim)
+        y = self.conv1.fuse(self.pad1(x), self.relu1, live, ring=RING)
+        return self.relu2(self.conv2(self.pad2(y), live), residual=t, trim=self.trim, ring=RING)
 
 
 class SphereConv2(nn.Module):
@@ -195,7 +203,7 @@ class SphereConv2(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.conv(self.pad(x), (self.ctx, x.shape[3] // 2), trim=self.trim)
+        return self.conv(self.pad(x), (self.ctx, x.shape[3] // 2), trim=self.trim, ring=RING)
 
 
 class EncoderV2(nn.Module):
@@ -242,7 +250,7 @@ class ResidualBlockUp(nn.Module):
         w = x.shape[3]
         br1 = self.dtow1(self.conv1.fuse(self.pad1(x), self.relu1, (self.ctx, w)))
         br2 = self.dtow2(self.short_cut(x, (self.ctx, w)))
-        return self.relu2(self.conv2(self.pad2(br1), (self.ctx, 2 * w)), residual=br2, trim=self.trim)
+        return self.relu2(self.conv2(self.pad2(br1), (self.ctx, 2 * w)), residual=br2, trim=self.trim, ring=RING)
 
 
 class SphereConvOld(nn.Module):
@@ -255,7 +263,7 @@ class SphereConvOld(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        return self.conv(x, (self.ctx, x.shape[3]), trim=self.trim)
+        return self.conv(x, (self.ctx, x.shape[3]), trim=self.trim, ring=RING)
 
 
 class DecoderV2(nn.Module):
