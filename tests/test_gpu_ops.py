@@ -322,3 +322,68 @@ def test_gdn_fused_matches_reference_formula(hip_backend, inverse):
     # dead columns are zero, the valid ones are not
     w0 = int(ctx.produce_fill_param(0, 8, 256)[0])
     assert fused[0, :, :, w0:].abs().sum() == 0 and fused[0, :, :, :w0].abs().sum() > 0
+
+
+@pytest.mark.parametrize("cfg", [(16, 192, 6, 130, 192, 3, 1), (16, 96, 4, 66, 192, 1, 1), (16, 192, 9, 131, 96, 3, 2)])
+def test_tile_conv_epilogue_and_views(cfg):
+    """the fused epilogue (sigmoid or PReLU, * gate, + residual, trim) is the oracle's
+    fmaf-chain convolution followed by the same element-wise operations, bit for bit
+    where no transcendental is involved; strided inputs / outputs (interior views of
+    padded buffers, `ring`) give the same values as dense tensors"""
+    tn, cin, h, w, cout, k, stride = cfg
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(tn, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g)
+    sl = torch.rand(cout, generator=g)
+    ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
+    res = torch.randn(tn, cout, ho, wo, generator=g)
+    gate = torch.randn(tn, cout, ho, wo, generator=g)
+    limit = torch.tensor([wo // 2, wo, wo - 3, 5] * 4, dtype=torch.int32)
+    owner = type("Owner", (), {})()
+    xg, wg, bg = x.to(DEV), wt.to(DEV), b.to(DEV)
+    # PReLU + residual + trim: exact
+    y = P().tile_conv2d(owner, xg, wg, bg, stride, sl.to(DEV), limit.to(DEV), 16, residual=res.to(DEV), trim=True)
+    ref = res + O.conv2d_chain(x, wt, b, stride, sl)
+    for t in range(tn):
+        ref[t, :, :, int(limit[t % 16]):] = 0
+    same(y, ref)
+    # sigmoid + gate + residual: the exponential differs from torch's in the last bits
+    y2 = P().tile_conv2d(owner, xg, wg, bg, stride, None, None, 0, sigmoid=True, gate=gate.to(DEV),
+                         residual=res.to(DEV)).cpu()
+    ref2 = res + gate * torch.sigmoid(O.conv2d_chain(x, wt, b, stride, None))
+    assert (y2 - ref2).abs().max().item() < 2e-6
+    # views: input, residual and gate inside padded buffers, output into a ring buffer
+    def inside(t, p):
+        buf = torch.full((t.shape[0], t.shape[1], t.shape[2] + 2 * p, t.shape[3] + 2 * p), float("nan"), device=DEV)
+        buf[:, :, p:-p, p:-p] = t.to(DEV)
+        return buf[:, :, p:-p, p:-p]
+    y3 = P().tile_conv2d(owner, inside(x, 2), wg, bg, stride, sl.to(DEV), limit.to(DEV), 16,
+                         residual=inside(res, 1), gate=inside(gate, 3), trim=True, ring=2)
+    assert not y3.is_contiguous() and y3._pconv_ring[1] == 2
+    y4 = P().tile_conv2d(owner, xg, wg, bg, stride, sl.to(DEV), limit.to(DEV), 16, residual=res.to(DEV),
+                         gate=gate.to(DEV), trim=True)
+    assert torch.equal(y3, y4)
+
+
+@pytest.mark.parametrize("shape,pad", [((16, 4, 16, 512), 1), ((16, 3, 8, 256), 2), ((32, 2, 2, 64), 2),
+                                       ((32, 2, 2, 64), 1)])
+def test_pseudo_pad_ring_equals_full_pad(shape, pad):
+    """PseudoPad of a tensor that already lives inside a padded buffer (only the ring is
+    written) against the copying pad of the same values, which is pinned to the oracle above"""
+    x = rnd(*shape, seed=5)
+    gctx = P().PseudoContextOp(16, 20, W16, 0, False)
+    xg = P().PseudoFillOp(0, 16, 0, 0, gctx.addr(), 0, 0, False).forward(x.clone().to(DEV))[0]
+    full = P().PseudoPadOp(pad, 16, gctx.addr(), 0, False).forward(xg)[0].clone()
+    store = 2
+    buf = torch.full((shape[0], shape[1], shape[2] + 2 * store, shape[3] + 2 * store), float("nan"), device=DEV)
+    view = buf[:, :, store:-store, store:-store]
+    view.copy_(xg)
+    view._pconv_ring = (buf, store)
+    op = P().PseudoPadOp(pad, 16, gctx.addr(), 0, False)
+    if pad < store:
+        # a wider pad used the buffer before: its wrap columns must not survive
+        P().PseudoPadOp(store, 16, gctx.addr(), 0, False).forward_ring(view)
+    ring = op.forward_ring(view)
+    assert ring.data_ptr() != full.data_ptr() and tuple(ring.shape) == tuple(full.shape)
+    assert torch.equal(ring, full)
