@@ -195,6 +195,8 @@ int pconv_gmm_loss(const float *weight, const float *delta, const float *mean,
  * product and the residual sum that follow the convolution in
  * model_zoo_v2.py:53,76,93,114,175) and, with trim != 0, zero from col_limit on
  * (the PseudoFill that ends every block).
+ * d2w != 0: DtowOp(2, d2w) (dtow_cuda.cu:38-75) applied by the store -- out is
+ * (tn, cout/4, 2*ho, 2*wo); only with act 0/1 and no gate / residual / trim.
  * views (may be NULL = all dense NCHW): 12 element strides, (tile, channel, row)
  * for in, out, residual, gate in this order; columns are always contiguous.
  * Lets a convolution write the interior of a padded buffer (whose ring
@@ -205,8 +207,8 @@ int pconv_conv_pack_weight(const float *w, float *packed, int cout, int cin, int
 int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
                  int tn, int cin, int h, int w, int cout, int k, int stride, int act,
                  const float *slope, const int32_t *col_limit, int npart,
-                 const float *residual, const float *gate, int trim, const long long *views,
-                 void *stream);
+                 const float *residual, const float *gate, int trim, int d2w,
+                 const long long *views, void *stream);
 
 /* PseudoGDNV2.forward (PseudoContextV2.py:133-216) in one launch on the same
  * kernel: out = in / sqrt(beta + gamma * in^2) over channels (inverse: in * sqrt),

@@ -955,13 +955,14 @@ FUSED_EPILOGUE = True  # tile_conv2d takes sigmoid / gate / residual / trim
 
 
 def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npart=0, sigmoid=False, gate=None,
-                residual=None, trim=False, ring=0):
+                residual=None, trim=False, ring=0, d2w=False):
     """y = conv2d(x, weight, bias, stride), no padding, on the fp32 matrix cores, then in
     the same launch PReLU(slope) or sigmoid, * gate, + residual, and (trim) zeros from
     each tile's col_limit on.  x (tn, cin, h, w) -> (tn, cout, ho, wo).  x, gate and
     residual may be interior views of padded buffers.  ring > 0: the result is written
     into the interior of a buffer padded by `ring` (returned as that view), so that a
-    following PseudoPad only has to fill the ring."""
+    following PseudoPad only has to fill the ring.  d2w: DtowOp(2, True) applied by the
+    store, the result is (tn, cout/4, 2*ho, 2*wo)."""
     x = _require_rows(x, "tile_conv2d")
     tn, cin, h, w = x.shape
     cout, cin_w, k, k2 = weight.shape
@@ -970,20 +971,22 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     stream = _stream(x.device)
     packed = packed_conv_weight(owner, weight, stream)
     ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
-    out = _ring_output((tn, cout, ho, wo), ring, x)
+    out = _ring_output((tn, cout // 4, 2 * ho, 2 * wo) if d2w else (tn, cout, ho, wo), ring, x)
     probe = conv_probe
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(x.device))
     if sigmoid and slope is not None:
         raise PconvError("tile_conv2d: PReLU and sigmoid are exclusive")
+    if d2w and (gate is not None or residual is not None or trim or sigmoid or cout % 4):
+        raise PconvError("tile_conv2d: d2w takes no sigmoid / gate / residual / trim and needs cout % 4 == 0")
     gate = _like_output(gate, out, "tile_conv2d: gate")
     residual = _like_output(residual, out, "tile_conv2d: residual")
     views = _views(x, out, residual, gate)
     call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
          tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
          _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
-         _ptr(residual), _ptr(gate), 1 if trim else 0, ctypes.addressof(views), stream)
+         _ptr(residual), _ptr(gate), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         tile = "192" if cout > 96 else ("96" if cout > 32 else "32")

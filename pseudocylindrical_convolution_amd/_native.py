@@ -43,7 +43,7 @@ _HIP_SIGNATURES = {
     "pconv_gmm_loss": [P, P, P, P, P, P, P, P, P, I, I, P],
     "pconv_conv_packed_size": [I, I, I, P, P],
     "pconv_conv_pack_weight": [P, P, I, I, I, P],
-    "pconv_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, P, P, I, P, P],
+    "pconv_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, P, P, I, I, P, P],
     "pconv_gdn": [P, P, P, P, I, I, I, I, I, P, I, P, P, P],
     # entropy wavefront
     "pconv_dinput2": [P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],

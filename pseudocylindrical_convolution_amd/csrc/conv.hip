@@ -67,6 +67,10 @@ struct ConvCfg {
 //   gate:      v = gate[.] * v        (attention: trunk * sigmoid(conv))
 //   residual:  v = residual[.] + v    (the "x + f(x)" of the residual blocks)
 //   trim:      v = 0 from the tile's col_limit on (PseudoFill of the block output)
+//   d2w:       the pixel shuffle of Dtow (dtow_cuda.cu:38-75) applied by the store: cout
+//              4c'+2sy+sx at (row, col) goes to channel c' at (2 row + sy, 2 col + sx); a
+//              lane holds the sx = 0/1 pair in neighbouring registers and stores it as one
+//              float2, so the wave still writes whole 256-byte runs
 // gate and residual have the output's shape.  This replaces up to four
 // element-wise passes over the activation that follow the convolution in the
 // reference's graph (sigmoid, mul, add, fill).
@@ -82,6 +86,7 @@ struct ConvEpilogue {
   const int32_t *col_limit;  // per latitude tile: first dead output column (may be null)
   int npart, act, trim;
   ConvView vres, vgate;
+  int d2w;  // depth-to-width x2 on the way out (DtowOp fused): out is (cout/4, 2*ho, 2*wo)
 };
 
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
@@ -127,8 +132,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     // tile lies entirely in the dead columns of this latitude band: zeros
     for (int e = tid; e < C::BM * kTileRows * kTileCols; e += kThreads) {
       const int col = e % kTileCols, row = (e / kTileCols) % kTileRows, co = e / (kTileCols * kTileRows);
-      if (cout0 + co < cout && r0 + row < ho && c0 + col < wo)
-        outp[(size_t)(cout0 + co) * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
+      if (cout0 + co < cout && r0 + row < ho && c0 + col < wo) {
+        const int cg = cout0 + co;
+        if (ep.d2w)
+          outp[(size_t)(cg >> 2) * vout.cs + (size_t)(2 * (r0 + row) + ((cg >> 1) & 1)) * vout.rs +
+               2 * (c0 + col) + (cg & 1)] = 0.f;
+        else
+          outp[(size_t)cg * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
+      }
     }
     return;
   }
@@ -274,6 +285,34 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
   const float *gatep = ep.gate ? ep.gate + (size_t)t * ep.vgate.ts : nullptr;
   // epilogue (see ConvEpilogue).  reg r of a 32x32 tile: cout row
   // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
+  if (ep.d2w) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int rp = 0; rp < 8; rp++) {
+        const int r = 2 * rp;  // registers r, r+1: couts co (even), co+1 = sx 0, 1
+        const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= cout) continue;
+        const float b0 = bias ? bias[co] : 0.f, b1 = bias ? bias[co + 1] : 0.f;
+        const float s0 = (act == 1) ? slope[co] : 0.f, s1 = (act == 1) ? slope[co + 1] : 0.f;
+        const int cq = co >> 2, sy = (co >> 1) & 1;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int seg = wn * NT + n;
+          const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+          if (orow < ho && ocol < wo) {
+            float2 v = make_float2(acc[m][n][r] + b0, acc[m][n][r + 1] + b1);
+            if (act == 1) {
+              if (v.x < 0) v.x = v.x * s0;
+              if (v.y < 0) v.y = v.y * s1;
+            }
+            *reinterpret_cast<float2 *>(outp + (size_t)cq * vout.cs + (size_t)(2 * orow + sy) * vout.rs + 2 * ocol) = v;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MT; m++) {
 #pragma unroll
@@ -390,9 +429,11 @@ extern "C" int pconv_conv_pack_weight(const float *w, float *packed, int cout, i
 extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float *bias, float *out,
                             int tn, int cin, int h, int w, int cout, int k, int stride, int act,
                             const float *slope, const int32_t *col_limit, int npart,
-                            const float *residual, const float *gate, int trim, const long long *views,
-                            void *stream) {
+                            const float *residual, const float *gate, int trim, int d2w,
+                            const long long *views, void *stream) {
   PCONV_REQUIRE(in && packed_w && out, "conv2d: null pointer");
+  PCONV_REQUIRE(!d2w || (cout % 4 == 0 && act <= 1 && !residual && !gate && !trim),
+                "conv2d: depth-to-width needs cout %% 4 == 0 and takes no sigmoid / gate / residual / trim");
   PCONV_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv2d: k=%d stride=%d unsupported",
                 k, stride);
   PCONV_REQUIRE(h >= k && w >= k && tn > 0 && cin > 0 && cout > 0, "conv2d: bad shape");
@@ -404,10 +445,14 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
   int cp, rp;
   pconv_conv_packed_size(cout, cin, k, &cp, &rp);
   hipStream_t s = as_stream(stream);
-  const ConvView vin = view_at(views, 0, cin, h, w), vout = view_at(views, 1, cout, ho, wo);
+  const int oc = d2w ? cout / 4 : cout, oh = d2w ? 2 * ho : ho, ow = d2w ? 2 * wo : wo;  // stored geometry
+  const ConvView vin = view_at(views, 0, cin, h, w), vout = view_at(views, 1, oc, oh, ow);
   const ConvEpilogue ep = {bias,  slope, residual, gate, col_limit, npart, act, trim,
-                           view_at(views, 2, cout, ho, wo), view_at(views, 3, cout, ho, wo)};
-  PCONV_REQUIRE(view_ok(vin, cin, h, w) && view_ok(vout, cout, ho, wo) &&
+                           view_at(views, 2, cout, ho, wo), view_at(views, 3, cout, ho, wo), d2w};
+  PCONV_REQUIRE(!d2w || (vout.rs % 2 == 0 && vout.cs % 2 == 0 && vout.ts % 2 == 0 &&
+                         (reinterpret_cast<uintptr_t>(out) & 7) == 0),
+                "conv2d: depth-to-width output must be 8-byte aligned row by row");
+  PCONV_REQUIRE(view_ok(vin, cin, h, w) && view_ok(vout, oc, oh, ow) &&
                     (!residual || view_ok(ep.vres, cout, ho, wo)) && (!gate || view_ok(ep.vgate, cout, ho, wo)),
                 "conv2d: strides overlap");
   PCONV_REQUIRE((long long)(16 - 1) * vin.cs + (long long)(h - 1) * vin.rs + w < (1LL << 32),
@@ -458,7 +503,7 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
   // views: in, out, residual
   const ConvView vin = view_at(views, 0, ch, h, w), vout = view_at(views, 1, ch, h, w);
   const ConvEpilogue ep = {beta, nullptr, residual, nullptr, col_limit, npart, inverse ? 3 : 2, 1,
-                           view_at(views, 2, ch, h, w), dense_view(ch, h, w)};
+                           view_at(views, 2, ch, h, w), dense_view(ch, h, w), 0};
   PCONV_REQUIRE(view_ok(vin, ch, h, w) && view_ok(vout, ch, h, w) && (!residual || view_ok(ep.vres, ch, h, w)),
                 "gdn: strides overlap");
   int rc;

@@ -52,6 +52,7 @@ class TileConv2d(nn.Conv2d):
       gate              y = gate * y          (attention: trunk * sigmoid(conv))
       residual          y = residual + y      (x + f(x) of the residual blocks)
       trim              the PseudoFill module that ends the block
+      d2w               the Dtow(2, True) module that follows (pixel shuffle done by the store)
       ring              write the result into the interior of a buffer padded by `ring`,
                         so that the PseudoPad of the consumer only fills the ring (no copy)
     `live=(ctx, base)` tells the kernel which output columns can ever be read: tile t
@@ -62,7 +63,8 @@ class TileConv2d(nn.Conv2d):
     PCONV_TILE_CONV=vendor for A/B timing -- never used for parity claims) the same
     operations run one by one, in the same order."""
 
-    def _native(self, x, prelu=None, live=None, sigmoid=False, gate=None, residual=None, trim=None, ring=0):
+    def _native(self, x, prelu=None, live=None, sigmoid=False, gate=None, residual=None, trim=None, ring=0,
+                d2w=None):
         ops = backend.ops()
         slope = prelu.weight if prelu is not None else None
         vendor = os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d")
@@ -78,7 +80,7 @@ class TileConv2d(nn.Conv2d):
         if fused and (trim is None or limit is not None):
             return ops.tile_conv2d(self, x, self.weight, self.bias, self.stride[0], slope, limit, npart,
                                    sigmoid=sigmoid, gate=gate, residual=residual, trim=trim is not None,
-                                   ring=ring)
+                                   ring=ring, d2w=d2w is not None)
         if vendor:
             y = nn.functional.conv2d(x, self.weight, self.bias, self.stride)
             y = nn.functional.prelu(y, slope) if slope is not None else y
@@ -90,6 +92,8 @@ class TileConv2d(nn.Conv2d):
             y = gate * y
         if residual is not None:
             y = residual + y
+        if d2w is not None:
+            y = d2w(y)
         return trim(y) if trim is not None else y
 
     def forward(self, x, live=None, **epilogue):
@@ -248,8 +252,8 @@ class ResidualBlockUp(nn.Module):
 
     def forward(self, x):
         w = x.shape[3]
-        br1 = self.dtow1(self.conv1.fuse(self.pad1(x), self.relu1, (self.ctx, w)))
-        br2 = self.dtow2(self.short_cut(x, (self.ctx, w)))
+        br1 = self.conv1.fuse(self.pad1(x), self.relu1, (self.ctx, w), d2w=self.dtow1, ring=RING)
+        br2 = self.short_cut(x, (self.ctx, w), d2w=self.dtow2)
         return self.relu2(self.conv2(self.pad2(br1), (self.ctx, 2 * w)), residual=br2, trim=self.trim, ring=RING)
 
 
@@ -284,6 +288,8 @@ class DecoderV2(nn.Module):
         self.__dict__["ctx"] = ctx
 
     def forward(self, x):
-        for m in self.net:
-            x = m(x, (self.ctx, x.shape[3] - 2)) if isinstance(m, TileConv2d) else m(x)
-        return x
+        mods = list(self.net)
+        for m in mods[:-2]:  # the blocks and the last pad
+            x = m(x)
+        # 3x3 conv to 12 channels + the depth-to-width that makes them 3 at full size
+        return mods[-2](x, (self.ctx, x.shape[3] - 2), d2w=mods[-1])

@@ -387,3 +387,24 @@ def test_pseudo_pad_ring_equals_full_pad(shape, pad):
     ring = op.forward_ring(view)
     assert ring.data_ptr() != full.data_ptr() and tuple(ring.shape) == tuple(full.shape)
     assert torch.equal(ring, full)
+
+
+@pytest.mark.parametrize("cfg", [(16, 192, 6, 70, 768, 3), (16, 192, 4, 64, 768, 1), (2, 192, 6, 70, 12, 3)])
+def test_tile_conv_depth_to_width_store(cfg):
+    """conv + PReLU + DtowOp(2, True) with the pixel shuffle done by the convolution's store
+    (dense and into a ring buffer) against the separate ops"""
+    tn, cin, h, w, cout, k = cfg
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(tn, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g)
+    sl = torch.rand(cout, generator=g)
+    owner = type("Owner", (), {})()
+    limit = torch.tensor([w - k + 1, 40, 64, 3] * 4, dtype=torch.int32).to(DEV)
+    for slope in (None, sl.to(DEV)):
+        plain = P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16)
+        shuffled = P().DtowOp(2, True, 0, False).forward(plain)[0]
+        for ring in (0, 2):
+            fused = P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16, d2w=True, ring=ring)
+            assert tuple(fused.shape) == tuple(shuffled.shape)
+            assert torch.equal(fused, shuffled)
