@@ -460,12 +460,12 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
   int rc;
 #define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, vin, vout, ep, s
   // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):
-  //   cout > 96 : 192 couts x (2 rows x 64 px), 4 waves of 96 x 64
+  //   cout > 96 : 192 couts x (2 rows x 64 px), 8 waves of 96 x 32 (4 waves of 96 x 64: -2 %)
   //   cout > 32 :  96 couts x (4 rows x 64 px), 8 waves of 96 x 32
   //   else      :  32 couts x (2 rows x 64 px), 4 waves of 32 x 32
 #define BY_TILE(KS, S, KC)                                         \
   if (cout > 96)                                                   \
-    rc = launch_conv<3, 2, 2, 2, KS, S, KC>(ARGS);                 \
+    rc = launch_conv<3, 1, 2, 4, KS, S, KC>(ARGS);                 \
   else if (cout > 32)                                              \
     rc = launch_conv<3, 1, 1, 8, KS, S, KC>(ARGS);                 \
   else                                                             \
@@ -508,7 +508,7 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
                 "gdn: strides overlap");
   int rc;
   if (ch > 96)
-    rc = launch_conv<3, 2, 2, 2, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
+    rc = launch_conv<3, 1, 2, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)
     rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else
