@@ -509,8 +509,14 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
     HIP_TRY(hipEventRecord(g.done, g.stream));
   }
   int status = 0;
+  const bool timing = getenv("PCONV_ENGINE_TIMING") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  double t_wait = 0, t_coder = 0;
   for (Group &g : e->groups) {
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(g.stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    t_wait += std::chrono::duration<double>(t1 - t0).count();
     for_each_image(g.nimg, [&](int i) {
       const int img = g.first + i;
       pconv_coder *c = e->coders[img];
@@ -531,7 +537,13 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
       const uint8_t *p = pconv_coder_bytes(c, &nb);
       e->streams[img].assign(p, p + nb);
     });
+    t_coder += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   }
+  if (timing)
+    fprintf(stderr, "[pconv engine] encode %d frame(s) in %d group(s): %.1f ms, of which GPU wait %.1f ms, coder %.1f ms\n",
+            e->nimg, (int)e->groups.size(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3, t_wait * 1e3,
+            t_coder * 1e3);
   PC_TRY(e->join(caller));
   return status < 0 ? PCONV_EINVAL : PCONV_OK;
 }

@@ -189,6 +189,22 @@ __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict
   for (int i = tid; i < N4; i += BLOCK) dst[i] = src[i];
 }
 
+// the same with the causal mask of output group tc applied: masked taps are staged
+// as zeros (fmaf(x, 0, acc) == acc for finite x), so the consumers need no test
+template <int CIN, int BLOCK>
+__device__ __forceinline__ void stage_weights_masked(float *wl, const float *__restrict__ wrow, int tid,
+                                                     int group_in, int causal_base) {
+  constexpr int N4 = slab_floats(CIN) / 4;
+  const float4 *src = reinterpret_cast<const float4 *>(wrow);
+  float4 *dst = reinterpret_cast<float4 *>(wl);
+  for (int kk = tid; kk < N4; kk += BLOCK) {
+    const int tap = kk / CIN, ci = kk - tap * CIN;
+    const int kh = tap / K, kw = tap - kh * K;
+    const bool ok = (2 * HALF - kh - kw) * group_in - ci + causal_base > 0;
+    dst[kk] = ok ? src[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // Step form: grid = 3 weight sets x planes of the step's window x images x `split`.
 // All positions of a plane share the output group, so the (set, group) weight slab
 // is fetched ONCE per workgroup, causally masked taps as zeros, together with the
@@ -387,14 +403,11 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   const int slack = (constrain == 5) ? 0 : 1;
   const int idx0 = (chunk * (BLOCK / kWave) + wave) * PP;
   unsigned off[ITER];  // byte offsets of this lane's taps inside a window
-  int lim[ITER];       // causal limit of the tap; very negative for lanes past the reduction length
   {
     TapWalk<CIN> tw(lane);
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
-      const bool in = lane + it * kWave < RED;
-      lim[it] = in ? tw.lim(group_in) : -(1 << 30);
-      off[it] = in ? 4u * (unsigned)tw.off(win) : 0u;
+      off[it] = (lane + it * kWave < RED) ? 4u * (unsigned)tw.off(win) : 0u;
       tw.next();
     }
   }
@@ -409,21 +422,24 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     for (int it = 0; it < ITER; it++) {
       unsigned o = off[it];
       asm volatile("" : "+v"(o));  // keeps the zero-extension out of a hoisted 64-bit add (see ee_conv_kernel)
-      xv[j][it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
+      const float v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
+      // lanes past the reduction length (last iteration only) contribute fmaf(0, w, acc) == acc
+      xv[j][it] = ((it + 1) * kWave <= RED || lane + it * kWave < RED) ? v : 0.f;
     }
     obase[j] = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
                 p.tw + pad_out) * cout;
   }
-  stage_weights<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x);
+  stage_weights_masked<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x, group_in,
+                                   slack * group_in);
   __syncthreads();
   for (int tc = 0; tc < g.ngroup; tc++) {
     // the next group's slab goes to the other buffer while this one is used (its
     // last readers passed the barrier that ended the previous iteration)
     if (tc + 1 < g.ngroup)
-      stage_weights<CIN, BLOCK>(wl2[(tc + 1) & 1], wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN),
-                                threadIdx.x);
+      stage_weights_masked<CIN, BLOCK>(wl2[(tc + 1) & 1],
+                                       wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN), threadIdx.x,
+                                       group_in, (tc + 1 + slack) * group_in);
     const float *wl = wl2[tc & 1];
-    const int causal_base = (tc + slack) * group_in;
     float acc[PP][GO];
 #pragma unroll
     for (int j = 0; j < PP; j++)
@@ -433,8 +449,7 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     for (int it = 0; it < ITER; it++) {
       const int kk = lane + it * kWave;
       const int kc = kk < RED ? kk : RED - 1;
-      float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);
-      if (!(lim[it] + causal_base > 0)) wv = make_float4(0.f, 0.f, 0.f, 0.f);  // fmaf(x, 0, acc) == acc
+      const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);  // causally masked taps are zeros
 #pragma unroll
       for (int j = 0; j < PP; j++) {
         acc[j][0] = fmaf(xv[j][it], wv.x, acc[j][0]);
@@ -634,13 +649,13 @@ int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float 
   // positions per wave (each staged weight slab then serves 16x as many): as many as
   // fit 128 registers beside the window (ITER values per position)
   const int iter = (cin * KK + kWave - 1) / kWave;
-  const int pp = iter <= 11 ? 4 : (iter <= 20 ? 3 : 1);
+  const int pp = iter <= 20 ? 4 : 1;
   const long long per_wg = kBlock / kWave * pp;
   const long long nchunk = (g->npos + per_wg - 1) / per_wg;
   const long long grid = (long long)3 * g->nimg * nchunk;
   PCONV_REQUIRE(grid > 0 && grid < (1LL << 31), "ee_conv_bulk: grid %lld out of range", grid);
 #define EE_BULK(CIN, ITER)                                                                                   \
-  hipLaunchKernelGGL((ee_conv_bulk_kernel<CIN, ITER, kBlock, (ITER <= 11 ? 4 : (ITER <= 20 ? 3 : 1))>), dim3((unsigned)grid), dim3(kBlock), 0,        \
+  hipLaunchKernelGGL((ee_conv_bulk_kernel<CIN, ITER, kBlock, (ITER <= 20 ? 4 : 1)>), dim3((unsigned)grid), dim3(kBlock), 0,        \
                      as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
                      pad_out)
   if (cin == 14) {
