@@ -10,7 +10,7 @@ authoring container:
                   outputs on seeded inputs (pure-torch files imported by path)
 
 The fixtures are data (inputs + expected outputs); no reference source is copied.
-Run from the repo root:  python tools/gen_golden.py
+Run from the repo root:  python tests/golden/gen_golden.py
 """
 import importlib.util
 import os
@@ -20,7 +20,7 @@ import tempfile
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")

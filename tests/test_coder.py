@@ -1,5 +1,5 @@
 """Arithmetic coder: product (libpconv_coder.so) vs the golden streams written by
-the REFERENCE coder (tests/golden/coder_*.npz, tools/gen_golden.py), vs the
+the REFERENCE coder (tests/golden/coder_*.npz, tests/golden/gen_golden.py), vs the
 bit-at-a-time oracle restatement, and -- when oracle/_ref is built -- vs the
 reference library live.  BASELINE config #1 is `uniform_32x32`."""
 import glob
