@@ -27,14 +27,10 @@ struct EeGeom {
   // read this interior column as one of their two sources
   const int32_t *rev_start, *rev_entry;
   // bulk (encoder) mode: every (plane, group) pair at once
-  const int32_t *bulk_wg;    // device, (plane, first position) per workgroup of kBulkPos positions
-  int nbulk_wg;
   const int32_t *pos_plane;  // device, plane of every schedule entry
   const int32_t *step_row;   // device, first table row of every step (rows are [step][img][l])
   int npos;
 };
-
-constexpr int kEeBulkPos = 8;  // positions per workgroup in bulk mode
 
 // weights (3, cout, cin, 5, 5) -> per (set, output group) a slab [tap*cin + ci][4]
 // with the group's 3 rows interleaved (entropy_engine.hip)

@@ -155,7 +155,7 @@ struct pconv_entropy_engine {
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
   int32_t *rev_start_d = nullptr, *rev_entry_d = nullptr;
   float *vh_wgt = nullptr;
-  int32_t *bulk_wg_d = nullptr, *pos_plane_d = nullptr;
+  int32_t *pos_plane_d = nullptr;
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
   const float *lb[kLayers] = {nullptr}, *la[kLayers] = {nullptr};
@@ -270,24 +270,14 @@ struct pconv_entropy_engine {
       HIP_TRY(hipMemcpy(rev_entry_d, rentry.data(), rentry.size() * 4, hipMemcpyHostToDevice));
     }
     EeGeom base = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, rev_start_d,
-                   rev_entry_d, nullptr, 0, nullptr, nullptr, 0};
+                   rev_entry_d, nullptr, nullptr, 0};
     {  // bulk (encoder) maps
       const int npos = sched_start[rows + w - 1];
-      std::vector<int32_t> wg, pp(npos);
-      for (int p = 0; p + 1 < rows + w; p++) {
-        const int cnt = sched_start[p + 1] - sched_start[p];
-        for (int i = 0; i < cnt; i++) pp[sched_start[p] + i] = p;
-        for (int f = 0; f < cnt; f += kEeBulkPos) {
-          wg.push_back(p);
-          wg.push_back(f);
-        }
-      }
-      HIP_TRY(hipMalloc(&bulk_wg_d, wg.size() * 4));
-      HIP_TRY(hipMemcpy(bulk_wg_d, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
+      std::vector<int32_t> pp(npos);
+      for (int p = 0; p + 1 < rows + w; p++)
+        for (int i = sched_start[p]; i < sched_start[p + 1]; i++) pp[i] = p;
       HIP_TRY(hipMalloc(&pos_plane_d, pp.size() * 4));
       HIP_TRY(hipMemcpy(pos_plane_d, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
-      base.bulk_wg = bulk_wg_d;
-      base.nbulk_wg = (int)(wg.size() / 2);
       base.pos_plane = pos_plane_d;
       base.npos = npos;
       stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
@@ -311,7 +301,7 @@ struct pconv_entropy_engine {
       if (p) (void)hipFree(p);
     };
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
-    freed(bulk_wg_d); freed(pos_plane_d); freed(rev_start_d); freed(rev_entry_d);
+    freed(pos_plane_d); freed(rev_start_d); freed(rev_entry_d);
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
     for (Group &g : groups) {
       freed(g.ctx); freed(g.packed); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
