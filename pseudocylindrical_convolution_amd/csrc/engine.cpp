@@ -285,11 +285,15 @@ struct pconv_entropy_engine {
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
     // two groups in ping-pong when there are frames for both (PCONV_ENGINE_GROUPS=1: A/B timing)
     int ngroups = nimg >= 2 ? 2 : 1;
-    if (const char *env = getenv("PCONV_ENGINE_GROUPS")) ngroups = (atoi(env) >= 2 && nimg >= 2) ? 2 : 1;
+    if (const char *env = getenv("PCONV_ENGINE_GROUPS")) ngroups = atoi(env);
+    if (ngroups > nimg) ngroups = nimg;
+    if (ngroups < 1) ngroups = 1;
     groups.resize(ngroups);
-    const int na = (nimg + ngroups - 1) / ngroups;
-    PC_TRY(init_group(groups[0], 0, na, base));
-    if (ngroups == 2) PC_TRY(init_group(groups[1], na, nimg - na, base));
+    for (int k = 0, first = 0; k < ngroups; k++) {
+      const int n = nimg / ngroups + (k < nimg % ngroups ? 1 : 0);
+      PC_TRY(init_group(groups[k], first, n, base));
+      first += n;
+    }
     HIP_TRY(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
     streams.resize(nimg);
     for (int i = 0; i < nimg; i++) coders.push_back(pconv_coder_new(nullptr));
