@@ -41,6 +41,11 @@ class EntropyEngine(object):
         for b in range(1, 6):
             convs += [ent.net[b].conv1.conv, ent.net[b].conv2.conv]
         convs.append(ent.net[6].conv)
+        signature = tuple((t.data_ptr(), t._version) for conv in convs
+                          for t in (conv.weight, conv.bias, conv.relu if conv.act else None) if t is not None)
+        if getattr(self, "_signature", None) == signature:
+            return  # same tensors, unmodified since the last bind
+        self._signature = signature
         self._params = []
         for layer, conv in enumerate(convs):
             tensors = [conv.weight, conv.bias, conv.relu if conv.act else None]

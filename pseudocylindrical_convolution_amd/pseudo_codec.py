@@ -188,6 +188,23 @@ class PseudoEncoder(nn.Module):
             return self.dtw(self.ext(code_i))
 
     def forward(self, x, code_name):
+        """x -> code file.  On the GPU the entropy stage runs on the native engine
+        (engine.EntropyEngine: one launch per layer over all wavefront steps); the file is
+        byte for byte what the op-by-op loop of `forward_per_op` writes
+        (tests/test_gpu_engine.py).  PCONV_ENTROPY=per-op forces the loop."""
+        with torch.no_grad():
+            hcode_i = self.symbols(x)
+            eng = _native_engine(self, "enc", hcode_i)
+            if eng is None:
+                self.ent.start(code_name)
+                self.ent(hcode_i)
+                return
+            stream = eng.encode(self.ent.fill(hcode_i).contiguous())[0]
+            with open(code_name, "wb") as f:
+                f.write(stream)
+
+    def forward_per_op(self, x, code_name):
+        """the reference's loop (pseudo_codec.py:97-114): ~36 op calls per wavefront step"""
         with torch.no_grad():
             hcode_i = self.symbols(x)
             self.ent.start(code_name)
@@ -220,10 +237,49 @@ class PseudoDecoder(nn.Module):
             return self.clip(self.uslice(self.decoder(code_f.contiguous())))
 
     def forward(self, code_name, height=512, width=1024):
+        """code file -> image; the entropy stage on the native engine when on the GPU
+        (see PseudoEncoder.forward)"""
+        with torch.no_grad():
+            h, w = latent_shape(height, width, self.npart)
+            eng = _native_engine(self, "dec", None, 2 * h, 2 * w)
+            if eng is None:
+                self.ent.start(code_name)
+                return self.reconstruct(self.ent(2 * h, 2 * w))
+            with open(code_name, "rb") as f:
+                stream = f.read()
+            return self.reconstruct(eng.decode([stream]))
+
+    def forward_per_op(self, code_name, height=512, width=1024):
+        """the reference's loop (pseudo_codec.py:145-160)"""
         with torch.no_grad():
             h, w = latent_shape(height, width, self.npart)
             self.ent.start(code_name)
             return self.reconstruct(self.ent(2 * h, 2 * w))
+
+
+def _native_engine(codec, which, symbols=None, h2=None, w2=None):
+    """single-frame EntropyEngine bound to codec.ent, cached on the codec per latent size;
+    None when the active backend has no native engine (the CPU oracle used by the tests)
+    or PCONV_ENTROPY=per-op asks for the op-by-op loops"""
+    import os
+    ops = backend.ops()
+    if os.environ.get("PCONV_ENTROPY", "native") == "per-op" or not getattr(ops, "FUSED_EPILOGUE", False):
+        return None
+    if symbols is not None:
+        if not symbols.is_cuda:
+            return None
+        h2, w2 = symbols.shape[2], symbols.shape[3]
+    from .engine import EntropyEngine
+    cache = codec.__dict__.setdefault("_pconv_engines", {})
+    key = (which, int(h2), int(w2))
+    if key not in cache:
+        dev = next(codec.ent.parameters()).device
+        if dev.type != "cuda":
+            return None
+        cache[key] = EntropyEngine(codec.ent, h2, w2, 1, dev)
+    else:
+        cache[key].bind(codec.ent)  # parameters may have been reloaded
+    return cache[key]
 
 
 # -- image / checkpoint I/O ---------------------------------------------------

@@ -33,16 +33,22 @@ def test_engine_stream_equals_per_op_path(hip_backend, tmp_path):
     eng = CodecEngine(56, 0, enc, dec)
     x = _frames(1, 256, 512)
     path = str(tmp_path / "ref.bin")
-    enc(x, path)
+    enc.forward_per_op(x, path)  # the reference's op-by-op loop
     streams = eng.encode(x)
     with open(path, "rb") as f:
+        assert streams[0] == f.read()
+    # the module's forward (native engine inside) writes the same file
+    fast = str(tmp_path / "fast.bin")
+    enc(x, fast)
+    with open(fast, "rb") as f:
         assert streams[0] == f.read()
     sym = eng.symbols(x)
     out = eng._engine("dec", sym.shape[2], sym.shape[3], 1).decode(streams)
     assert torch.equal(out, sym)
     rec_engine = eng.decode(streams, 256, 512)
-    rec_per_op = dec(path, 256, 512)
+    rec_per_op = dec.forward_per_op(path, 256, 512)
     assert torch.equal(rec_engine, rec_per_op)
+    assert torch.equal(dec(fast, 256, 512), rec_per_op)
 
 
 def test_engine_lockstep_batch_equals_single_frames(hip_backend):
