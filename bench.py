@@ -109,7 +109,9 @@ def cpu_baseline(sample_h, sample_w):
         dt = time.perf_counter() - t0
     finally:
         backend.reset()
-    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": torch.get_num_threads(),
+    cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") \
+        else torch.get_num_threads()
+    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": cores,
             "kind": "port",
             "sample": "1 frame %dx%d enc+dec, %.1f s (oracle C kernels + torch CPU conv)" % (sample_w, sample_h, dt)}
 
