@@ -11,14 +11,17 @@
 //   * engine-private channels-last buffers whose halos are written by the
 //     producer of the value they derive from (entropy_engine.hip);
 //   * the frames of a call advance in lock-step inside a GROUP, one arithmetic
-//     coder each, and a call with two or more frames runs two groups in
-//     ping-pong: each group has its own buffers and HIP stream, and while the
-//     host decodes the symbols of group A's step the GPU evaluates group B's
-//     (the decoder alternates a GPU phase and a CPU phase per step; one group
-//     alone leaves each processor idle during the other's phase);
-//   * only the live rows of a step cross PCIe, through pinned buffers; the
-//     encoder never waits inside the loop: tables and labels of all steps are
-//     written to one device buffer in stream order, copied once and coded.
+//     coder each; a call with several frames is split into 2 groups with
+//     their own buffers, HIP stream and (in the decoder) host thread: a group's
+//     step is a latency chain -- 14 back-to-back launches, host wait, arithmetic
+//     decoding -- that leaves the GPU mostly idle, so the chains run side by
+//     side (measured: 4 independent chains cost 25 % more time than one; beyond
+//     the 4 hardware queues they start to wait for each other);
+//   * only the live rows of a step cross PCIe: the decoder's table kernel writes
+//     them straight into pinned host memory and its scatter kernel reads the
+//     decoded symbols from there (no copy launches inside a step); the encoder
+//     never waits inside the loop: tables and labels of all steps are written to
+//     one device buffer in stream order, copied once and coded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -135,10 +138,9 @@ struct Group {
   hipEvent_t done = nullptr;
   float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
   float *act[kLayers] = {nullptr};  // (3*nimg*npart, h+2p, w+2p, 3G), persistent across steps
-  float *packed = nullptr;          // decoder: symbols of the previous step [img][len]
   int32_t *tables_d = nullptr, *labels_d = nullptr;
   int32_t *tables_h = nullptr, *labels_h = nullptr;  // pinned
-  float *packed_h = nullptr;                         // pinned
+  float *packed_h = nullptr;                         // pinned; decoder: symbols of the previous step [img][len]
   int32_t *step_row_d = nullptr;
   std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
   std::vector<int32_t> sym;
@@ -199,7 +201,6 @@ struct pconv_entropy_engine {
     g.geom.step_row = g.step_row_d;
     HIP_TRY(hipMalloc(&g.ctx, ctx_elems(n) * 4));
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&g.act[l], act_elems(l, n) * 4));
-    HIP_TRY(hipMalloc(&g.packed, (size_t)n * max_len * 4));
     const size_t all_rows = sym_per_img * n;
     HIP_TRY(hipMalloc(&g.tables_d, all_rows * (nlevels + 1) * 4));
     HIP_TRY(hipMalloc(&g.labels_d, all_rows * 4));
@@ -283,7 +284,9 @@ struct pconv_entropy_engine {
       stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
     }
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
-    // two groups in ping-pong when there are frames for both (PCONV_ENGINE_GROUPS=1: A/B timing)
+    // decoder chains run side by side, one per group.  Two groups by default: in the
+    // entropy probe four are 3-5 % faster at 4-8 frames, in the whole codec (bench.py)
+    // 4 % slower; eight make the chains wait for each other (4 hardware queues)
     int ngroups = nimg >= 2 ? 2 : 1;
     if (const char *env = getenv("PCONV_ENGINE_GROUPS")) ngroups = atoi(env);
     if (ngroups > nimg) ngroups = nimg;
@@ -308,7 +311,7 @@ struct pconv_entropy_engine {
     freed(pos_plane_d); freed(rev_start_d); freed(rev_entry_d);
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
     for (Group &g : groups) {
-      freed(g.ctx); freed(g.packed); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
+      freed(g.ctx); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
       for (int l = 0; l < kLayers; l++) freed(g.act[l]);
       if (g.tables_h) (void)hipHostFree(g.tables_h);
       if (g.labels_h) (void)hipHostFree(g.labels_h);
@@ -401,14 +404,16 @@ struct pconv_entropy_engine {
   // decoder, GPU phase of step s for one group (everything is queued, nothing waits)
   int decode_enqueue(Group &g, int s, const Window &prev, const Window &cur) {
     const int cols = nlevels + 1;
-    if (s > 0) PC_TRY(ee_scatter(&g.geom, g.packed, g.ctx, prev.lo, prev.len, s - 1, -bias, g.stream));
+    // Zero-copy both ways: the scatter kernel reads the decoded symbols from the pinned host
+    // buffer and the table kernel writes its rows into pinned host memory (both are
+    // device-visible), which removes two copy launches and their gaps from every step.
+    if (s > 0) PC_TRY(ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, s - 1, -bias, g.stream));
     if (cur.len > 0) {
-      const size_t nrow = (size_t)cur.len * g.nimg;
       PC_TRY(network_step(g, s, cur));
-      PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_d, nullptr, cur.lo, cur.len, s, nlevels, bias,
+      PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_h, nullptr, cur.lo, cur.len, s, nlevels, bias,
                        total, beta, g.stream));
-      HIP_TRY(hipMemcpyAsync(g.tables_h, g.tables_d, nrow * cols * 4, hipMemcpyDeviceToHost, g.stream));
     }
+    (void)cols;
     return PCONV_OK;
   }
 
@@ -435,7 +440,6 @@ struct pconv_entropy_engine {
       pconv_set_error("ee_decode: arithmetic decoder desynchronised at step %d", s);
       return PCONV_EINVAL;
     }
-    HIP_TRY(hipMemcpyAsync(g.packed, g.packed_h, nrow * 4, hipMemcpyHostToDevice, g.stream));
     const auto t2 = std::chrono::steady_clock::now();
     *t_wait += std::chrono::duration<double>(t1 - t0).count();
     *t_coder += std::chrono::duration<double>(t2 - t1).count();
@@ -562,47 +566,64 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
     }
   // PCONV_ENGINE_TIMING=1: where the decoder's wall time goes, printed once per call
   const bool timing = getenv("PCONV_ENGINE_TIMING") != nullptr;
-  double t_wait = 0, t_coder = 0;
   const auto t_begin = std::chrono::steady_clock::now();
   PC_TRY(e->fork(caller));
-  for (Group &g : e->groups) g.pool = new StepPool(g.nimg);
-  int rc = PCONV_OK;
-  for (Group &g : e->groups)
-    if (rc >= 0) rc = e->clear(g);
-  // ping-pong: while the host decodes step s-1 of one group, the GPU runs the
-  // other group's step; a group's step s is queued as soon as its step s-1 symbols are back
-  Window prev = {0, 0, 0, 0};
-  for (int s = 0; s <= e->nsteps && rc >= 0; s++) {
-    const Window cur = s < e->nsteps ? e->window(s) : Window{0, 0, 0, 0};
-    for (Group &g : e->groups) {
-      if (s > 0 && rc >= 0) rc = e->decode_symbols(g, s - 1, prev, &t_wait, &t_coder);
-      if (rc < 0) break;
-      if (s < e->nsteps) {
-        rc = e->decode_enqueue(g, s, prev, cur);
-      } else {
-        // the symbols of the last step have not been scattered by a following step yet
-        rc = ee_scatter(&g.geom, g.packed, g.ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, g.stream);
-        if (rc >= 0)
-          rc = ee_read_symbols(&g.geom, g.ctx, symbols_out + (size_t)g.first * e->image_symbols(), e->bias, g.stream);
-      }
+  // One host thread per group.  A group's step is a chain -- 14 back-to-back launches,
+  // table copy, host wait, arithmetic decoding, symbol copy, next step -- of which the
+  // GPU part is latency-bound and the host part serial, so the chains of the groups
+  // simply run side by side: every group has its own stream, pinned buffers, coders and
+  // now its own driver, and nothing orders one group's step against another's.
+  const int ng = (int)e->groups.size();
+  std::vector<int> rcs(ng, PCONV_OK);
+  std::vector<std::string> errors(ng);
+  std::vector<double> waits(ng, 0.0), coders(ng, 0.0);
+  auto drive = [&](int k) {
+    Group &g = e->groups[k];
+    StepPool pool(g.nimg);
+    g.pool = &pool;
+    int rc = e->clear(g);
+    Window prev = {0, 0, 0, 0};
+    for (int s = 0; s < e->nsteps && rc >= 0; s++) {
+      const Window cur = e->window(s);
+      rc = e->decode_enqueue(g, s, prev, cur);
+      if (rc >= 0) rc = e->decode_symbols(g, s, cur, &waits[k], &coders[k]);
+      prev = cur;
     }
-    prev = cur;
-  }
-  for (Group &g : e->groups) {
-    delete g.pool;
+    // the symbols of the last step have not been scattered by a following step yet
+    if (rc >= 0) rc = ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, g.stream);
+    if (rc >= 0)
+      rc = ee_read_symbols(&g.geom, g.ctx, symbols_out + (size_t)g.first * e->image_symbols(), e->bias, g.stream);
+    if (rc < 0) {
+      errors[k] = pconv_last_error();  // the message lives in this thread
+      (void)hipStreamSynchronize(g.stream);
+    }
     g.pool = nullptr;
+    rcs[k] = rc;
+  };
+  {
+    std::vector<std::thread> drivers;
+    for (int k = 1; k < ng; k++) drivers.emplace_back(drive, k);
+    drive(0);
+    for (std::thread &t : drivers) t.join();
   }
-  if (rc < 0) {
-    for (Group &g : e->groups) (void)hipStreamSynchronize(g.stream);
-    return rc;
-  }
+  for (int k = 0; k < ng; k++)
+    if (rcs[k] < 0) {
+      pconv_set_error("%s", errors[k].c_str());
+      for (Group &g : e->groups) (void)hipStreamSynchronize(g.stream);
+      return rcs[k];
+    }
   PC_TRY(e->join(caller));
   if (timing) {
     const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    double w = 0, c = 0;
+    for (int k = 0; k < ng; k++) {
+      w += waits[k] / ng;
+      c += coders[k] / ng;
+    }
     fprintf(stderr,
-            "[pconv engine] decode %d frame(s) in %d group(s), %d steps: host loop %.1f ms, of which GPU wait %.1f ms, "
+            "[pconv engine] decode %d frame(s) in %d group(s), %d steps: %.1f ms; per group driver: GPU wait %.1f ms, "
             "coder %.1f ms\n",
-            e->nimg, (int)e->groups.size(), e->nsteps, all * 1e3, t_wait * 1e3, t_coder * 1e3);
+            e->nimg, ng, e->nsteps, all * 1e3, w * 1e3, c * 1e3);
   }
   return PCONV_OK;
 }
