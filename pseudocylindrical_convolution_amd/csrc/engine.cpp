@@ -577,7 +577,16 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
   std::vector<int> rcs(ng, PCONV_OK);
   std::vector<std::string> errors(ng);
   std::vector<double> waits(ng, 0.0), coders(ng, 0.0);
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
   auto drive = [&](int k) {
+    // a new thread starts on device 0: bind it to the engine's GPU (ranks of a
+    // multi-GPU job each drive their own device)
+    if (hipSetDevice(device) != hipSuccess) {
+      errors[k] = "ee_decode: hipSetDevice failed in a group driver";
+      rcs[k] = PCONV_ELAUNCH;
+      return;
+    }
     Group &g = e->groups[k];
     StepPool pool(g.nimg);
     g.pool = &pool;
