@@ -61,6 +61,45 @@ __device__ __forceinline__ float butterfly_sum(float v) {
   return v;
 }
 
+// The same butterfly for 12 values at once (4 positions x 3 outputs of the bulk kernel).
+// A plain butterfly repeats every exchange in both partners; here a step keeps each
+// pair's sum in only one of them and uses the freed half for another value, so the 12
+// reductions take 6 + 3 + 2 + 1 + 1 + 1 exchange-adds instead of 72.  Every value still
+// goes through the pairs (l, l^32), (l, l^16), ... (l, l^1) in that order -- the sums
+// are the same IEEE additions, bit for bit.  Result, per lane: the total of
+// v[lane >> 4][{0, 2, 1, 2}[(lane >> 2) & 3]] (rows = positions, quads = outputs).
+__device__ __forceinline__ float butterfly12(const float (&v)[4][GO], int lane) {
+  // xor 32: pair value i (kept in lanes 0-31) with value i+6 (lanes 32-63)
+  float a[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int i0 = k, i1 = k + 6;
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i0 / GO][i0 % GO]),
+                                              __float_as_uint(v[i1 / GO][i1 % GO]), false, false);
+    a[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  // xor 16: rows (16 lanes) 0..3 <- values k, k+3, k+6, k+9
+  float b[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[k]), __float_as_uint(a[k + 3]), false, false);
+    b[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  // xor 8 inside a row; lanes 0-7 of a row keep output 0, lanes 8-15 output 1; output 2 alone
+  float c[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    c[k] = b[k] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b[k]), 0x128, 0xF, 0xF, false));
+  const float c01 = (lane & 8) ? c[1] : c[0];
+  // xor 4; lanes with bit 2 clear keep outputs 0 / 1, the others output 2
+  const float d01 = c01 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(c01), 0x101F));
+  const float d2 = c[2] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(c[2]), 0x101F));
+  float t = (lane & 4) ? d2 : d01;
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));  // xor 2
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));  // xor 1
+  return t;
+}
+
 // Packed weights: for every (set, output group) one slab [kk][4] holding the GO = 3
 // rows of the group interleaved (4th float is padding), kk = tap*cin + ci.  A lane
 // then fetches its three weights of a tap with one 16-byte LDS read.
@@ -457,22 +496,38 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
         acc[j][2] = fmaf(xv[j][it], wv.z, acc[j][2]);
       }
     }
-    const int pout = tc * GO + (lane < GO ? lane : 0);
-    const int bidx = set * cout + pout;
-    const float bv = bias[bidx];
-    const float sv = slope ? slope[bidx] : 0.f;
+    if constexpr (PP == 4) {
+      // all 12 reductions at once; lane L ends with position L >> 4, output {0,2,1,2}[quad]
+      const float tot = butterfly12(acc, lane);
+      const int j = lane >> 4, quad = (lane >> 2) & 3;
+      const int o = quad == 0 ? 0 : (quad == 2 ? 1 : 2);
+      if ((lane & 3) == 0 && quad != 3 && idx0 + j < g.npos) {
+        const int pout = tc * GO + o;
+        const int bidx = set * cout + pout;
+        const size_t ob = j == 0 ? obase[0] : (j == 1 ? obase[1] : (j == 2 ? obase[2] : obase[3]));
+        float v = tot + bias[bidx];
+        if (slope && v < 0) v = v * slope[bidx];
+        if (residual) v = v + residual[ob + pout];
+        y[ob + pout] = v;
+      }
+    } else {
+      const int pout = tc * GO + (lane < GO ? lane : 0);
+      const int bidx = set * cout + pout;
+      const float bv = bias[bidx];
+      const float sv = slope ? slope[bidx] : 0.f;
 #pragma unroll
-    for (int j = 0; j < PP; j++) {
+      for (int j = 0; j < PP; j++) {
 #pragma unroll
-      for (int o = 0; o < GO; o++) acc[j][o] = butterfly_sum(acc[j][o]);
-      if (idx0 + j < g.npos && lane < GO) {
-        float v = acc[j][0];
+        for (int o = 0; o < GO; o++) acc[j][o] = butterfly_sum(acc[j][o]);
+        if (idx0 + j < g.npos && lane < GO) {
+          float v = acc[j][0];
 #pragma unroll
-        for (int o = 1; o < GO; o++) v = (lane == o) ? acc[j][o] : v;
-        v = v + bv;
-        if (slope && v < 0) v = v * sv;
-        if (residual) v = v + residual[obase[j] + pout];
-        y[obase[j] + pout] = v;
+          for (int o = 1; o < GO; o++) v = (lane == o) ? acc[j][o] : v;
+          v = v + bv;
+          if (slope && v < 0) v = v * sv;
+          if (residual) v = v + residual[obase[j] + pout];
+          y[obase[j] + pout] = v;
+        }
       }
     }
     __syncthreads();
