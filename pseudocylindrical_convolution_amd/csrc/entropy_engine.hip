@@ -61,6 +61,27 @@ __device__ __forceinline__ float butterfly_sum(float v) {
   return v;
 }
 
+// The three outputs of one position in one packed butterfly: 7 exchange-adds instead
+// of 18, same pairs and order per value.  Result per lane: the total of output
+// {0, 2, 1, 2}[lane >> 4] (rows of 16 lanes).
+__device__ __forceinline__ float butterfly3(float v0, float v1, float v2) {
+  float a01, a2;
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+    a01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lanes 0-31: v0, lanes 32-63: v1
+    const unsigned u = __float_as_uint(v2);
+    auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a2 = __uint_as_float(q[0]) + __uint_as_float(q[1]);   // v2 in both halves
+  }
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a01), __float_as_uint(a2), false, false);
+  float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows: v0, v2, v1, v2
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // xor 8
+  t += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t), 0x101F));                      // xor 4
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));   // xor 2
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));   // xor 1
+  return t;
+}
+
 // The same butterfly for 12 values at once (4 positions x 3 outputs of the bulk kernel).
 // A plain butterfly repeats every exchange in both partners; here a step keeps each
 // pair's sum in only one of them and uses the freed half for another value, so the 12
@@ -374,37 +395,30 @@ __global__ __launch_bounds__(BLOCK, WLDS ? 8 : waves_per_eu(ITER)) void ee_conv_
         a2 = fmaf(xv[it], w2[it], a2);
       }
     }
-    a0 = butterfly_sum(a0);
-    a1 = butterfly_sum(a1);
-    a2 = butterfly_sum(a2);
-    // every lane finishes all three outputs (the halo lanes below need them)
-    float v0 = a0 + b0, v1 = a1 + b1, v2 = a2 + b2;
+    // one packed butterfly; the row of 16 lanes a lane sits in decides which output it
+    // finishes (rows 0 / 2 / 1,3 -> outputs 0 / 1 / 2), and the epilogue is spread the same way
+    const int row = lane >> 4;
+    const int o = row == 0 ? 0 : (row == 2 ? 1 : 2);
+    float v = butterfly3(a0, a1, a2) + (o == 0 ? b0 : (o == 1 ? b1 : b2));
     if (slope) {
-      v0 = v0 < 0 ? v0 * s0 : v0;
-      v1 = v1 < 0 ? v1 * s1 : v1;
-      v2 = v2 < 0 ? v2 * s2 : v2;
+      const float sl = o == 0 ? s0 : (o == 1 ? s1 : s2);
+      v = v < 0 ? v * sl : v;
     }
-    if (rimg) {
-      v0 = v0 + r0;
-      v1 = v1 + r1;
-      v2 = v2 + r2;
-    }
-    const float mine = lane == 0 ? v0 : (lane == 1 ? v1 : v2);
-    if (lane < GO) yimg[oflat + lane] = mine;
+    if (rimg) v = v + (o == 0 ? r0 : (o == 1 ? r1 : r2));
+    const bool writer = (lane & 15) == 0 && row != 3;  // one lane per output
+    if (writer) yimg[oflat + o] = v;
     if (pad_out) {
       const int valid = g.widths[p.tg];
-      if (p.tw < PAD && lane < GO) yimg[oflat + (size_t)valid * cout + lane] = mine;  // circular wrap copy
+      if (p.tw < PAD && writer) yimg[oflat + (size_t)valid * cout + o] = v;  // circular wrap copy
       if (p.th < PAD || p.th >= h - PAD) {
-        // this value feeds halo rows of the neighbouring tiles
+        // this value feeds halo rows of the neighbouring tiles: the 16 lanes of a row
+        // share the entries that read it
         const int grow = p.tg * h + p.th;
         const int key = grow * w + p.tw;
-        const int r0 = g.rev_start[key], n = g.rev_start[key + 1] - r0;
-        for (int j0 = 0; j0 < n; j0 += kWave / GO) {
-          const int j = j0 + lane / GO, o = lane % GO;
-          if (lane < (kWave / GO) * GO && j < n)
-            halo_write<true>(g, yimg, cout, pout0 + o, g.rev_entry[r0 + j], grow, p.tw,
-                             o == 0 ? v0 : (o == 1 ? v1 : v2));
-        }
+        const int rs = g.rev_start[key], n = g.rev_start[key + 1] - rs;
+        if (row != 3)
+          for (int k = lane & 15; k < n; k += 16)
+            halo_write<true>(g, yimg, cout, pout0 + o, g.rev_entry[rs + k], grow, p.tw, v);
       }
     }
   }
