@@ -5,16 +5,27 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One step = every rank encodes and decodes its own shard of frames
-(--frames-per-gpu, independent frames, no data-path collective: weak scaling).
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+With --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N
+ranks itself (torch.distributed.run as a child, before anything here touches the
+GPU) and exits with their code.  One step = every rank encodes and decodes its
+own shard of frames (--frames-per-gpu, independent frames, no data-path
+collective: weak scaling).  Rank 0 prints ONE JSON line.  Besides the contract
+fields it carries
   roofline      the dominant kernel (fp32-MFMA tile conv, 3x3 stride-1, 192-cout
-                tile) timed with events on its launch stream during the timed steps
+                tile) timed with events on its launch stream during the timed
+                steps; `traffic` / `mfma_busy` from the rocprofv3 --pmc summary
+                under profiles/ when that summary is of the same kernel
   cpu_baseline  the CPU oracle port of the same codec on a bounded sample
+
+--mode analysis times the analysis transform alone (BASELINE config #3:
+SphereSlice + EncoderV2, 1x3x1024x2048) and reports a roofline table per kernel
+class instead.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -29,18 +40,53 @@ import torch.distributed as dist
 VALID_FRACTION = 836.0 / 1024.0      # valid columns / all columns
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md, dense fp32 matrix peak
 MODEL_VALID_DIM = 56                 # model-idx 3 of the --ssim list (pseudo_codec.py:18-19)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_bench_pmc.json")
 
 
+# ----------------------------------------------------------------------------
+# launcher
+# ----------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(nproc, argv, script=None, env=None):
+    """Start `nproc` ranks of `script` (this file) under torch.distributed.run, one per
+    GPU, and return their exit code.  The caller must not have initialised the GPU: the
+    ranks are CHILD processes (never an exec of this one), each picks its device from
+    LOCAL_RANK before its first HIP call."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           script or os.path.abspath(__file__)] + list(argv)
+    child_env = dict(os.environ)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child_env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(nproc, 1))))
+    if env:
+        child_env.update(env)
+    return subprocess.call(cmd, env=child_env)
+
+
+# ----------------------------------------------------------------------------
+# workload pieces
+# ----------------------------------------------------------------------------
 def make_codec(device_id, vd=MODEL_VALID_DIM):
+    """seeded random-weight codec in a FIXED state: eval mode (the quantiser's training-mode
+    level merge, pseudo_quant_cuda.cu:97-143, must not fire inside a benchmark) and the
+    decoder's level table tied to the encoder's"""
     from pseudocylindrical_convolution_amd import pseudo_codec as PC
     torch.manual_seed(1234)
-    enc, dec = PC.PseudoEncoder(vd, device_id), PC.PseudoDecoder(vd, device_id)
+    enc, dec = PC.PseudoEncoder(vd, device_id).eval(), PC.PseudoDecoder(vd, device_id).eval()
     g = torch.Generator().manual_seed(7)
     # the reference's default torch.rand init makes degenerate CDFs (SURVEY 8d)
     sd = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in enc.ent.state_dict().items()}
     enc.ent.load_state_dict(sd)
     dec.ent.load_state_dict(sd)
-    dec.quant.weight.data.copy_(enc.quant.weight.data)
+    with torch.no_grad():
+        dec.quant.weight.copy_(enc.quant.weight)
     return enc, dec
 
 
@@ -60,7 +106,8 @@ def synthetic_frame(h, w, seed, device):
 
 
 class ConvProbe(object):
-    """collects (kernel key, flops, start event, end event) of tile-conv launches"""
+    """collects the tile-conv / GDN launches of the timed steps: PCONV appends
+    (kernel, class label, algorithmic flops, start event, end event)"""
 
     def __init__(self):
         self.records = []
@@ -68,147 +115,291 @@ class ConvProbe(object):
     def summarise(self):
         torch.cuda.synchronize()
         per = {}
-        for key, flops, e0, e1 in self.records:
+        for kernel, label, flops, e0, e1 in self.records:
+            d = per.setdefault(kernel, {"flops": 0.0, "seconds": 0.0, "launches": 0, "classes": {}})
             t = e0.elapsed_time(e1) * 1e-3
-            d = per.setdefault(key, [0.0, 0.0, 0])
-            d[0] += flops
-            d[1] += t
-            d[2] += 1
+            d["flops"] += flops
+            d["seconds"] += t
+            d["launches"] += 1
+            c = d["classes"].setdefault(label, [0.0, 0.0, 0])
+            c[0] += flops
+            c[1] += t
+            c[2] += 1
         return per
 
 
-def pmc_traffic(avg_algorithmic_flops):
-    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from
-    inside this process; profiles/round1_conv_pmc.json holds the rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE measurement (corrected as MI355X_MICROARCH.md prescribes) of
-    the half-resolution 192->192 3x3 launch, scaled here by flops to the average launch
-    of the timed steps (the kernel's bytes per flop do not depend on the image scale)."""
-    path = os.path.join(ROOT, "profiles", "round1_conv_pmc.json")
-    if not os.path.exists(path):
+def pmc_evidence(kernel, avg_flops):
+    """HBM bytes per launch and matrix-pipe busy fraction of `kernel` from the tracked
+    rocprofv3 --pmc summary (tools/summarise_pmc.py over separate counter passes of this
+    very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC counters
+    cannot be read from inside the process; a summary of another kernel is not used."""
+    if not os.path.exists(PMC_SUMMARY):
         return {}
-    with open(path) as f:
+    with open(PMC_SUMMARY) as f:
         pmc = json.load(f)
-    per_flop = pmc["bytes_per_launch"]["total_dead_skipped"] / (pmc["flops_all_columns"] * VALID_FRACTION)
-    return {"traffic": round(per_flop * avg_algorithmic_flops),
-            "traffic_source": "profiles/round1_conv_pmc.json (rocprofv3 --pmc, scaled by flops)"}
+    rec = pmc.get("kernels", {}).get(kernel)
+    if not rec:
+        return {}
+    out = {"traffic_source": "profiles/%s" % os.path.basename(PMC_SUMMARY)}
+    if rec.get("hbm_bytes_per_launch") is not None:
+        out["traffic"] = int(rec["hbm_bytes_per_launch"])
+        if rec.get("algorithmic_flops_per_launch"):
+            # same kernel, possibly a different mix of launch sizes: scale by flops
+            out["traffic"] = int(rec["hbm_bytes_per_launch"] * avg_flops / rec["algorithmic_flops_per_launch"])
+    if rec.get("mfma_busy") is not None:
+        out["mfma_busy"] = rec["mfma_busy"]
+    return out
 
 
 def cpu_baseline(sample_h, sample_w):
-    """CPU oracle port of the same encode+decode on one bounded frame"""
+    """CPU oracle port of the same encode+decode on one bounded frame, all host threads
+    torch is given; transform / entropy splits as BASELINE.md section 2 asks"""
     from pseudocylindrical_convolution_amd.PCONV_operator import backend
+    from pseudocylindrical_convolution_amd.pseudo_codec import latent_shape
     from oracle import pconv_cpu, coder_cpu
     backend.use(pconv_cpu, coder_cpu)
     pconv_cpu.set_detmath(True)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 32))     # oneDNN on these small tensors stops scaling long before 128
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
     try:
         enc, dec = make_codec(0)
         x = synthetic_frame(sample_h, sample_w, 100, "cpu")
         path = os.path.join(tempfile.mkdtemp(), "cpu.bin")
+        h, w = latent_shape(sample_h, sample_w)
         t0 = time.perf_counter()
-        enc(x, path)
-        dec(path, sample_h, sample_w)
-        dt = time.perf_counter() - t0
+        sym = enc.symbols(x)
+        t1 = time.perf_counter()
+        enc.ent.start(path)
+        enc.ent(sym)
+        t2 = time.perf_counter()
+        dec.ent.start(path)
+        back = dec.ent(2 * h, 2 * w)
+        t3 = time.perf_counter()
+        dec.reconstruct(back)
+        t4 = time.perf_counter()
+        assert torch.equal(back, enc.ent.fill(sym)), "CPU baseline: decoded symbols differ"
     finally:
+        torch.set_num_threads(before)
         backend.reset()
-    cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") \
-        else torch.get_num_threads()
-    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": cores,
-            "kind": "port",
-            "sample": "1 frame %dx%d enc+dec, %.1f s (oracle C kernels + torch CPU conv)" % (sample_w, sample_h, dt)}
+    dt = t4 - t0
+    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": threads, "kind": "port",
+            "sample": "1 frame %dx%d enc+dec, %.1f s (oracle C kernels single-threaded + torch CPU conv on %d threads)"
+                      % (sample_w, sample_h, dt, threads),
+            "split_s": {"analysis": round(t1 - t0, 2), "entropy_encode": round(t2 - t1, 2),
+                        "entropy_decode": round(t3 - t2, 2), "synthesis": round(t4 - t3, 2)}}
 
 
-def main():
+class CodecWorkload(object):
+    """BASELINE config #5's per-GPU share: F frames encoded and decoded per step on the
+    native engine; frames resident in HBM, streams in host memory"""
+
+    name = "codec"
+
+    def __init__(self, args, rank, local, dev):
+        from pseudocylindrical_convolution_amd.engine import CodecEngine
+        self.H, self.W, self.F = args.height, args.width, args.frames_per_gpu
+        self.enc, self.dec = make_codec(local)
+        self.codec = CodecEngine(MODEL_VALID_DIM, local, self.enc, self.dec)
+        self.frames = torch.cat([synthetic_frame(self.H, self.W, 100 + rank * self.F + i, dev)
+                                 for i in range(self.F)], 0)
+        self.bits_first, self.bits, self.rec, self.streams = None, 0, None, None
+        self.local = local
+
+    def step(self):
+        # frames of the shard are coded in lock-step; streams stay in host memory
+        self.streams = self.codec.encode(self.frames)
+        self.rec = self.codec.decode(self.streams, self.H, self.W)
+        self.bits = sum(len(s) for s in self.streams) * 8
+        if self.bits_first is None:
+            self.bits_first = self.bits
+
+    def pixels_per_step(self):
+        return float(self.F) * self.H * self.W
+
+    def check(self):
+        """after the timed loop: the workload was stationary (same bits as the first timed
+        step) and the decoder returned exactly the symbols the encoder coded"""
+        assert self.bits == self.bits_first, "bitstream size changed during the run (%d -> %d bits)" % (
+            self.bits_first, self.bits)
+        sym = self.codec.symbols(self.frames)
+        eng = self.codec._engine("dec", sym.shape[2], sym.shape[3], self.F)
+        assert torch.equal(eng.decode(self.streams), sym), "decoded symbols differ from the encoded ones"
+        from pseudocylindrical_convolution_amd.pseudo_codec import ViewportMetrics
+        metrics = ViewportMetrics(self.local)
+        psnr = ssim = 0.0
+        for i in range(self.F):
+            p, s = metrics(self.frames[i:i + 1], self.rec[i:i + 1])
+            psnr += p
+            ssim += s
+        return {"psnr_sum": psnr, "ssim_sum": ssim}
+
+    def describe(self):
+        return "ERP %dx%d encode+decode, model-idx 3 --ssim (valid_dim 56), %d frame(s)/GPU/step" % (
+            self.W, self.H, self.F)
+
+
+class AnalysisWorkload(object):
+    """BASELINE config #3: SphereSlice + EncoderV2 forward only"""
+
+    name = "analysis"
+
+    def __init__(self, args, rank, local, dev):
+        self.H, self.W, self.F = args.height, args.width, args.frames_per_gpu
+        self.enc, _ = make_codec(local)
+        self.frames = [synthetic_frame(self.H, self.W, 100 + rank * self.F + i, dev) for i in range(self.F)]
+        self.bits = 0
+        self.code = None
+
+    @torch.no_grad()
+    def step(self):
+        for x in self.frames:
+            self.code = self.enc.encoder(self.enc.slice(x))
+
+    def pixels_per_step(self):
+        return float(self.F) * self.H * self.W
+
+    def check(self):
+        assert self.code is not None and torch.isfinite(self.code).all()
+        assert tuple(self.code.shape) == (16, 192, self.H // 256, self.W // 16)
+        return {}
+
+    def describe(self):
+        return "analysis transform only (SphereSlice + EncoderV2: 4x pseudo-conv stages + GDN), ERP %dx%d, %d frame(s)/GPU/step" % (
+            self.W, self.H, self.F)
+
+
+WORKLOADS = {"codec": CodecWorkload, "analysis": AnalysisWorkload}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--height", type=int, default=2048)
-    ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--frames-per-gpu", type=int, default=8,
+    ap.add_argument("--mode", choices=sorted(WORKLOADS), default="codec")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--frames-per-gpu", type=int, default=None,
                     help="frames each rank codes per step, in lock-step through the entropy wavefront")
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed passes before the warm-up so that the caching allocator reaches steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="256x512", help="HxW of the CPU baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample", default="512x1024", help="HxW of the CPU baseline sample")
+    ap.add_argument("--no-check", action="store_true", help="skip the round-trip / stationarity assertions")
+    args = ap.parse_args(argv)
+    if args.height is None:
+        args.height = 2048 if args.mode == "codec" else 1024
+    if args.width is None:
+        args.width = 4096 if args.mode == "codec" else 2048
+    if args.frames_per_gpu is None:
+        args.frames_per_gpu = 8 if args.mode == "codec" else 1
+    return args
 
+
+def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
+    """one rank of the benchmark (the whole job when WORLD_SIZE is 1)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = device_type == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local)   # before the first HIP call of this rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
-    torch.cuda.set_device(local)
-    dev = "cuda:%d" % local
+        dist.init_process_group(backend=dist_backend)
+    dev = "cuda:%d" % local if on_gpu else "cpu"
+    n_joined = dist.get_world_size() if world > 1 else 1
 
-    from pseudocylindrical_convolution_amd import PCONV
-    from pseudocylindrical_convolution_amd.engine import CodecEngine
-    enc, dec = make_codec(local)
-    codec = CodecEngine(MODEL_VALID_DIM, local, enc, dec)
-    H, W, F = args.height, args.width, args.frames_per_gpu
-    frames = torch.cat([synthetic_frame(H, W, 100 + rank * F + i, dev) for i in range(F)], 0)
-    state = {"bits": 0}
-
-    def step():
-        # frames of the shard are coded in lock-step; streams stay in host memory
-        streams = codec.encode(frames)
-        rec = codec.decode(streams, H, W)
-        state["bits"] = sum(len(s) for s in streams) * 8
-        return rec
+    load = (workload_cls or WORKLOADS[args.mode])(args, rank, local, dev)
 
     def fence():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.prime + args.warmup):
-        step()
-    probe = ConvProbe()
-    PCONV.conv_probe = probe
+        load.step()
+    load.bits_first = None
+    probe = None
+    if on_gpu:
+        from pseudocylindrical_convolution_amd import PCONV
+        probe = ConvProbe()
+        PCONV.conv_probe = probe
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        load.step()
     fence()
     elapsed = time.perf_counter() - t0
-    PCONV.conv_probe = None
-    from pseudocylindrical_convolution_amd import sharding
-    totals, elapsed = sharding.reduce_metrics(
-        {"pixels": float(F * args.steps) * H * W, "bits": float(state["bits"]), "frames": float(F)}, elapsed, dev)
+    if on_gpu:
+        PCONV.conv_probe = None
+    extra = {} if args.no_check else load.check()
 
-    per_kernel = probe.summarise()
-    total_pix = totals["pixels"]
-    bits = totals["bits"] / world
+    from pseudocylindrical_convolution_amd import sharding
+    local_sums = {"pixels": load.pixels_per_step() * args.steps, "bits": float(load.bits), "frames": float(load.F)}
+    local_sums.update(extra)
+    totals, elapsed = sharding.reduce_metrics(local_sums, elapsed, dev)
+
     out = None
     if rank == 0:
-        dom_key = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None
-        roof = None
-        if dom_key is not None:
-            fl, tt, n = per_kernel[dom_key]
-            ach = fl / tt / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel[%s]" % dom_key, "achieved": round(ach, 2),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "launches": n, "avg_launch_ms": round(tt / n * 1e3, 4), "traffic": None}
-            roof.update(pmc_traffic(fl / n))
-        conv_s = sum(v[1] for v in per_kernel.values()) / max(args.steps, 1)
+        per_kernel = probe.summarise() if probe is not None else {}
+        roof, table = None, []
+        for kernel, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]["seconds"]):
+            for label, (fl, tt, n) in sorted(d["classes"].items(), key=lambda kv: -kv[1][1]):
+                table.append({"class": label, "kernel": kernel, "launches": n, "avg_launch_ms": round(tt / n * 1e3, 4),
+                              "gflop_per_launch": round(fl / n / 1e9, 3), "achieved": round(fl / tt / 1e12, 2),
+                              "frac": round(fl / tt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)})
+        if per_kernel:
+            kernel = max(per_kernel, key=lambda k: per_kernel[k]["seconds"])
+            d = per_kernel[kernel]
+            ach = d["flops"] / d["seconds"] / 1e12
+            roof = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "launches": d["launches"],
+                    "avg_launch_ms": round(d["seconds"] / d["launches"] * 1e3, 4), "traffic": None}
+            roof.update(pmc_evidence(kernel, d["flops"] / d["launches"]))
+        conv_s = sum(v["seconds"] for v in per_kernel.values()) / max(args.steps, 1)
+        frames_total = max(totals["frames"], 1.0)
+        config = {"workload": load.describe(), "frames_per_gpu": load.F,
+                  "parallelism": "frames sharded, no data-path collective",
+                  "tile_conv_s_per_step": round(conv_s, 4)}
+        if load.name == "codec":
+            config["bpp"] = round(totals["bits"] / (frames_total * load.H * load.W), 4)
+            if not args.no_check:
+                config["viewport_psnr_db"] = round(totals["psnr_sum"] / frames_total, 3)
+                config["viewport_ssim"] = round(totals["ssim_sum"] / frames_total, 5)
+                config["roundtrip"] = "decoded symbols == encoded symbols, bits constant over the timed steps"
+        metric = "ERP MPix/s enc+dec, 4096x2048 model-idx 3" if load.name == "codec" else \
+            "ERP MPix/s analysis transform only, %dx%d" % (load.W, load.H)
         out = {
-            "metric": "ERP MPix/s enc+dec, 4096x2048 model-idx 3", "value": round(total_pix / elapsed / 1e6, 4),
-            "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": round(totals["pixels"] / elapsed / 1e6, 4),
+            "unit": "MPix/s", "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ERP %dx%d encode+decode, model-idx 3 --ssim (valid_dim 56), %d frame(s)/GPU/step"
-                                   % (W, H, F), "frames_per_gpu": F, "bpp": round(bits / float(F * H * W), 4),
-                       "parallelism": "frames sharded, no data-path collective",
-                       "tile_conv_s_per_step": round(conv_s, 4)},
-            "roofline": roof,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if load.name == "analysis" or os.environ.get("PCONV_BENCH_TABLE"):
+            out["roofline_table"] = table
+        if world == 1 and on_gpu and not args.no_cpu_baseline and load.name == "codec":
             sh, sw = (int(v) for v in args.cpu_sample.split("x"))
             out["cpu_baseline"] = cpu_baseline(sh, sw)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: become the launcher.  Nothing above has touched HIP
+        # (importing torch does not), and the ranks are children, not an exec of this process.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
+    run(args)
 
 
 if __name__ == "__main__":

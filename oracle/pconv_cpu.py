@@ -376,8 +376,11 @@ class PseudoQuantOp(_Base):
         quant = np.zeros(x.numel(), np.int32)
         val = self._top(0, x.shape)
         idx = self._top(1, x.shape) if self.ntop_ > 1 else None
-        lib().orc_quant_forward(_p(x), _p(weight.detach().contiguous()), _p(tab), _p(quant), _p(val), _p(idx), None,
-                                _p(hidx), I(num), I(c), I(h), I(w), I(self.bin_num_), I(self.npart_))
+        # count_data_: per-call histogram, -1 per valid element (pseudo_quant_cuda.cu:12,64,83,167)
+        self.count_data_ = torch.zeros((c, self.bin_num_), dtype=torch.float32)
+        lib().orc_quant_forward(_p(x), _p(weight.detach().contiguous()), _p(tab), _p(quant), _p(val), _p(idx),
+                                _p(self.count_data_), _p(hidx), I(num), I(c), I(h), I(w), I(self.bin_num_),
+                                I(self.npart_))
         return [val, idx] if idx is not None else [val]
 
 

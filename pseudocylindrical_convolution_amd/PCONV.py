@@ -484,6 +484,7 @@ class PseudoQuantOp(_Op):
         self.ntop_ = int(ntop)
         self.weight_decay_, self.mod_ = float(weight_decay), int(check_iters)
         self.iter_ = 0
+        self.count_data_ = None
         self.ctx_ = _lookup(addr)
 
     def update_weight(self, weight, ncount):
@@ -520,8 +521,13 @@ class PseudoQuantOp(_Op):
         tab = self._out("tab", (c, self.bin_num_), x)
         val = self._out(0, x.shape, x)
         idx = self._out(1, x.shape, x) if self.ntop_ > 1 else None
-        call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), None, _ptr(wd),
-             tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
+        # per-call histogram of the levels hit, -1 per valid element: the op's own
+        # count_data_ (pseudo_quant_cuda.cu:12,64,83,167), zeroed on every call; the
+        # reference hands it to autograd as the "gradient" of the module's `count`
+        self.count_data_ = self._out("count", (c, self.bin_num_), x)
+        self.count_data_.zero_()
+        call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), _ptr(self.count_data_),
+             _ptr(wd), tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
         if train:
             self.iter_ += 1
         return [val, idx] if idx is not None else [val]
@@ -875,8 +881,10 @@ def conv_col_limit(ctx_op, h, base, extra, like):
 
 def packed_conv_weight(owner, weight, stream):
     """[k][cout] fp32 slab of a conv weight for pconv_conv2d, cached on `owner`
-    until the parameter is modified."""
-    key = (weight.data_ptr(), weight._version, weight.device)
+    until the parameter is modified (in place, by load_state_dict, or -- for writes
+    through `.data` -- after backend.invalidate_derived())."""
+    from .PCONV_operator import backend
+    key = (weight.data_ptr(), weight._version, weight.device, backend.param_epoch())
     cached = getattr(owner, "_pconv_packed", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -888,11 +896,19 @@ def packed_conv_weight(owner, weight, stream):
     return packed
 
 
-# when set to an object with a `records` list, every tile-conv launch is bracketed by
-# events on its own stream: (kernel key, algorithmic flops, start, end).  Used by
-# bench.py for the live roofline figure; None in normal operation.
+# when set to an object with a `records` list, every tile-conv / GDN launch is bracketed
+# by events on its own stream: (kernel instantiation, class label, algorithmic flops,
+# start, end).  Used by bench.py for the live roofline figures; None in normal operation.
 conv_probe = None
 _VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack
+
+
+def conv_kernel_name(cout, k, stride, squared=False):
+    """the conv_mfma_kernel instantiation pconv_conv2d / pconv_gdn pick for a layer
+    (csrc/conv.hip, BY_TILE): <MT, NT, WM, WN, KS, S, KC, SQ> as rocprofv3 prints it"""
+    mt, nt, wm, wn = (3, 1, 2, 4) if cout > 96 else ((3, 1, 1, 8) if cout > 32 else (1, 1, 1, 4))
+    return "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>" % (mt, nt, wm, wn, k, stride, 16 if k == 1 else 4,
+                                                                "true" if squared else "false")
 
 
 def _like_output(t, out, what):
@@ -946,8 +962,16 @@ def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=N
     out = _ring_output((tn, ch, h, w), ring, x)
     residual = _like_output(residual, out, "tile_gdn: residual")
     views = _views(x, out, residual)
+    probe = conv_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(x.device))
     call("pconv_gdn", _ptr(x), _ptr(packed), _ptr(beta.detach().contiguous()), _ptr(out), tn, ch, h, w,
          1 if inverse else 0, _ptr(col_limit), int(npart), _ptr(residual), ctypes.addressof(views), stream)
+    if probe is not None:
+        e1.record(torch.cuda.current_stream(x.device))
+        probe.records.append((conv_kernel_name(ch, 1, 1, True), "GDN %d" % ch,
+                              2.0 * ch * ch * tn * h * w * _VALID_FRACTION, e0, e1))
     return out
 
 
@@ -989,7 +1013,7 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
          _ptr(residual), _ptr(gate), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
-        tile = "192" if cout > 96 else ("96" if cout > 32 else "32")
         flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
-        probe.records.append(("k%d s%d cout-tile %s" % (k, stride, tile), flops, e0, e1))
+        probe.records.append((conv_kernel_name(cout, k, stride), "%dx%d s%d %d->%d" % (k, k, stride, cin, cout),
+                              flops, e0, e1))
     return out

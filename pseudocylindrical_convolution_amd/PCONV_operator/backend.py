@@ -47,3 +47,28 @@ def device_of(gid):
     """torch device string an op keyed by `gid` works on under the active backend."""
     mod = ops()
     return getattr(mod, "DEVICE_FMT", "cuda:{}").format(gid)
+
+
+# -- derived-parameter caches ---------------------------------------------------
+# Packed convolution slabs, the effective GDN parameters and the entropy engine's
+# repacked weights are cached per parameter tensor, keyed on (data_ptr, _version).
+# A write through `.data` does not bump `_version`, so every cache key also
+# carries this epoch: `invalidate_derived()` drops them all at once, and the codec
+# modules call it from a load_state_dict post-hook (`watch_state_dict`).
+_param_epoch = [0]
+
+
+def param_epoch():
+    return _param_epoch[0]
+
+
+def invalidate_derived():
+    """Drop every cache derived from module parameters (call after editing a
+    parameter through `.data`; load_state_dict does it by itself)."""
+    _param_epoch[0] += 1
+
+
+def watch_state_dict(module):
+    """make `module.load_state_dict` invalidate the derived caches"""
+    module.register_load_state_dict_post_hook(lambda mod, incompatible: invalidate_derived())
+    return module

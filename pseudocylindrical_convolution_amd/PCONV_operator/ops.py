@@ -198,7 +198,7 @@ class PseudoGDNV2(nn.Module):
     def effective(self):
         """(gamma, beta) after the lower-bound re-parametrisation, cached until a
         parameter changes"""
-        key = (self.gamma._version, self.beta._version, self.gamma.device)
+        key = (self.gamma._version, self.beta._version, self.gamma.device, backend.param_epoch())
         if getattr(self, "_effective", (None,))[0] != key:
             with torch.no_grad():
                 pedestal = self.pedestal.to(self.gamma.device)

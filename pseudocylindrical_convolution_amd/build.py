@@ -64,6 +64,11 @@ def _stale(target, deps_mtime):
     return (not os.path.exists(target)) or os.path.getmtime(target) < deps_mtime
 
 
+def _older_than(lib, objs):
+    """a library is relinked when it is missing or older than any of its own objects"""
+    return (not os.path.exists(lib)) or any(os.path.getmtime(lib) < os.path.getmtime(o) for o in objs)
+
+
 def _run(cmd):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -73,8 +78,13 @@ def _run(cmd):
 
 
 def _compile(src, flags, cc, hdr_time, as_hip):
+    # one object directory per toolchain: coder.cpp is compiled twice (hipcc for the
+    # engine inside libpconv_hip.so, g++ for libpconv_coder.so) and the two objects
+    # must never stand in for each other
     path = os.path.join(CSRC, src)
-    obj = os.path.join(OBJ, src + ".o")
+    objdir = os.path.join(OBJ, "hip" if as_hip else "cxx")
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, src + ".o")
     if _stale(obj, max(os.path.getmtime(path), hdr_time)):
         cmd = [cc] + flags
         if as_hip and src.endswith(".cpp"):
@@ -97,7 +107,7 @@ def build(verbose=False, jobs=4):
         res = list(ex.map(lambda s: _compile(s, HIP_FLAGS, cc, hdr, True), sources))
     objs = [o for o, _ in res]
     lib = os.path.join(HERE, "libpconv_hip.so")
-    if any(ch for _, ch in res) or not os.path.exists(lib):
+    if any(ch for _, ch in res) or _older_than(lib, objs):
         _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)
         if verbose:
             print("linked", lib)
@@ -106,7 +116,7 @@ def build(verbose=False, jobs=4):
         raise RuntimeError("no host C++ compiler found for libpconv_coder.so")
     cres = [_compile(s, CXX_FLAGS, cxx, hdr, False) for s in CODER_SOURCES]
     clib = os.path.join(HERE, "libpconv_coder.so")
-    if any(ch for _, ch in cres) or not os.path.exists(clib):
+    if any(ch for _, ch in cres) or _older_than(clib, [o for o, _ in cres]):
         _run([cxx, "-shared", "-fPIC", "-o", clib] + [o for o, _ in cres])
         if verbose:
             print("linked", clib)

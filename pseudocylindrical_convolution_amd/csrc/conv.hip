@@ -24,6 +24,7 @@
 // Numerics contract: every output is ONE k-ascending fmaf chain starting at 0
 // (the MFMA accumulates k0 then k1 into the same register, chunks continue the
 // chain), then + bias, then the activation.  The oracle restates exactly that.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -374,14 +375,22 @@ int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, i
   }
   const size_t smem = (size_t)2 * C::STAGE * sizeof(float);
   auto kern = conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>;
-  static bool raised = false;
-  if (smem > 64 * 1024 && !raised) {
-    raised = true;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) {
-      pconv_set_error("conv2d: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e));
-      return PCONV_ELAUNCH;
+  if (smem > 64 * 1024) {
+    // the dynamic-LDS limit is a per-device attribute of the function: raise it once on
+    // every device this process launches the instantiation on (one process may drive
+    // several GPUs: nn.DataParallel replicas of BaseOpModule)
+    static std::atomic<unsigned long long> raised{0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+    const unsigned long long bit = 1ULL << (device & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) {
+        pconv_set_error("conv2d: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e));
+        return PCONV_ELAUNCH;
+      }
+      raised.fetch_or(bit, std::memory_order_release);
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, out, cin, h, w, cout,

@@ -29,7 +29,9 @@
 #include <string.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -69,16 +71,20 @@ inline void cpu_relax() {
 
 // Persistent helpers for the per-step arithmetic decoding: job(i) runs for
 // i = 0 (caller) .. n-1 (workers).  A step's decoding takes tens of microseconds,
-// far less than creating and joining threads, so the workers spin on a
-// generation counter for the duration of one decode call.
+// far less than creating and joining threads, so the workers poll a generation
+// counter -- but only for a bounded time (PCONV_ENGINE_SPIN_US, default 60 us:
+// about the host part of a step).  A worker that sees nothing for that long blocks
+// on a condition variable, so the GPU waits of the steps do not keep nimg - 1 cores
+// per group busy (8 ranks x 8 frames would otherwise be ~60 runnable threads).
 class StepPool {
  public:
   explicit StepPool(int n) : n_(n) {
+    if (const char *env = getenv("PCONV_ENGINE_SPIN_US")) spin_us_ = atoi(env);
     for (int i = 1; i < n_; i++) workers_.emplace_back([this, i] { loop(i); });
   }
   ~StepPool() {
     stop_.store(true, std::memory_order_release);
-    gen_.fetch_add(1, std::memory_order_release);
+    publish();
     for (std::thread &t : workers_) t.join();
   }
   void run(const std::function<void(int)> &job) {
@@ -88,21 +94,32 @@ class StepPool {
     }
     job_ = &job;
     done_.store(0, std::memory_order_relaxed);
-    gen_.fetch_add(1, std::memory_order_release);
+    publish();
     job(0);
     while (done_.load(std::memory_order_acquire) < n_ - 1) cpu_relax();
   }
 
  private:
+  void publish() {
+    gen_.fetch_add(1, std::memory_order_release);
+    if (sleepers_.load(std::memory_order_acquire) > 0) {
+      std::lock_guard<std::mutex> lk(mu_);
+      cv_.notify_all();
+    }
+  }
   void loop(int i) {
     int seen = 0;
     for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
       int spins = 0;
       while (gen_.load(std::memory_order_acquire) == seen) {
         cpu_relax();
-        if (++spins > 4096) {
-          std::this_thread::yield();
-          spins = 0;
+        if ((++spins & 255) == 0 &&
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us_) {
+          std::unique_lock<std::mutex> lk(mu_);
+          sleepers_.fetch_add(1, std::memory_order_acq_rel);
+          cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+          sleepers_.fetch_sub(1, std::memory_order_acq_rel);
         }
       }
       seen = gen_.load(std::memory_order_acquire);
@@ -112,10 +129,13 @@ class StepPool {
     }
   }
   int n_;
+  int spin_us_ = 60;
   std::vector<std::thread> workers_;
   const std::function<void(int)> *job_ = nullptr;
-  std::atomic<int> gen_{0}, done_{0};
+  std::atomic<int> gen_{0}, done_{0}, sleepers_{0};
   std::atomic<bool> stop_{false};
+  std::mutex mu_;
+  std::condition_variable cv_;
 };
 
 template <typename Fn>
@@ -506,7 +526,10 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
     PC_TRY(e->encode_tables(g, symbols));
     HIP_TRY(hipEventRecord(g.done, g.stream));
   }
-  int status = 0;
+  // the per-image coder threads report through an atomic and per-image strings; the
+  // thread-local error slot is written by the calling thread after the joins
+  std::atomic<int> status{0};
+  std::vector<std::string> errors(e->nimg);
   const bool timing = getenv("PCONV_ENGINE_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   double t_wait = 0, t_coder = 0;
@@ -527,8 +550,8 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
       }
       if (rc >= 0) rc = pconv_coder_end_encoder(c);
       if (rc < 0) {
-        status = rc;
-        pconv_set_error("ee_encode: coder of image %d: %s", img, pconv_coder_error(c));
+        status.store(rc, std::memory_order_relaxed);
+        errors[img] = std::string("ee_encode: coder of image ") + std::to_string(img) + ": " + pconv_coder_error(c);
         return;
       }
       size_t nb = 0;
@@ -543,7 +566,15 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3, t_wait * 1e3,
             t_coder * 1e3);
   PC_TRY(e->join(caller));
-  return status < 0 ? PCONV_EINVAL : PCONV_OK;
+  if (status.load() < 0) {
+    for (const std::string &m : errors)
+      if (!m.empty()) {
+        pconv_set_error("%s", m.c_str());
+        break;
+      }
+    return PCONV_EINVAL;
+  }
+  return PCONV_OK;
 }
 
 const uint8_t *pconv_ee_stream(const pconv_entropy_engine *e, int img, size_t *nbytes) {

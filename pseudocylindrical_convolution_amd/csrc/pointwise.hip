@@ -63,7 +63,23 @@ __global__ __launch_bounds__(kBlock) void quant_kernel(
         val = v - tmp;
         q = j;
       }
-      if (count) atomicAdd(count + pc * levels + q, -1.0f);
+    }
+    if (count) {
+      // per-call histogram (pseudo_quant_cuda.cu:64,83: atomicAdd(count + pc*levels + j, -1.0)).
+      // The sums are integers far below 2^24, so any order gives the same bits: the lanes
+      // of a wave that hit the same (channel, level) add once, with their number.
+      const bool live = pw < widths[pg];
+      const int slot = live ? pc * levels + q : -1;
+      const int first = __builtin_amdgcn_readfirstlane(pc);
+      if (__all(pc == first)) {
+        for (int lv = 0; lv < levels; lv++) {
+          const unsigned long long hit = __ballot(live && q == lv);
+          if (hit && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(hit))
+            atomicAdd(count + first * levels + lv, -(float)__popcll(hit));
+        }
+      } else if (slot >= 0) {
+        atomicAdd(count + slot, -1.0f);
+      }
     }
     out_val[i] = val;
     if (out_idx) out_idx[i] = (float)q;

@@ -14,7 +14,7 @@ import torch
 
 from . import _native
 from ._native import PconvError, call
-from .PCONV_operator import set_weight
+from .PCONV_operator import backend, set_weight
 from . import pseudo_codec as PC
 
 
@@ -41,8 +41,9 @@ class EntropyEngine(object):
         for b in range(1, 6):
             convs += [ent.net[b].conv1.conv, ent.net[b].conv2.conv]
         convs.append(ent.net[6].conv)
-        signature = tuple((t.data_ptr(), t._version) for conv in convs
-                          for t in (conv.weight, conv.bias, conv.relu if conv.act else None) if t is not None)
+        signature = (backend.param_epoch(),) + tuple(
+            (t.data_ptr(), t._version) for conv in convs
+            for t in (conv.weight, conv.bias, conv.relu if conv.act else None) if t is not None)
         if getattr(self, "_signature", None) == signature:
             return  # same tensors, unmodified since the last bind
         self._signature = signature
@@ -115,9 +116,14 @@ class CodecEngine(object):
 
     def _engine(self, which, h, w, nimg):
         key = (which, h, w, nimg)
+        ent = self.enc.ent if which == "enc" else self.dec.ent
         if key not in self._engines:
-            ent = self.enc.ent if which == "enc" else self.dec.ent
             self._engines[key] = EntropyEngine(ent, h, w, nimg, self.device)
+        else:
+            # the engine owns repacked copies of the weights: re-bind on every fetch
+            # (a no-op while the parameters are unchanged) so that a reloaded or edited
+            # entropy model can never run on stale slabs
+            self._engines[key].bind(ent)
         return self._engines[key]
 
     @torch.no_grad()

@@ -226,6 +226,7 @@ class EncoderV2(nn.Module):
         self.act = nn.Sigmoid()
         self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
         self.__dict__["ctx"] = ctx
+        backend.watch_state_dict(self)  # packed conv slabs / GDN parameters follow a reload
 
     def forward(self, x):
         for m in self.net[:-1]:
@@ -286,6 +287,7 @@ class DecoderV2(nn.Module):
             Dtow(2, True, device_id),
         )
         self.__dict__["ctx"] = ctx
+        backend.watch_state_dict(self)
 
     def forward(self, x):
         mods = list(self.net)

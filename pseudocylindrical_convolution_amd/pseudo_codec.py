@@ -25,6 +25,7 @@ from .PCONV_operator import (DExtract2, DExtract2Batch, DInput2, Dtow, EntropyAd
                              PseudoContextV2, PseudoDQUANT, PseudoFillV2, PseudoQUANTV2, SphereSlice,
                              SphereUslice, SSIM, backend)
 from .model_zoo_v2 import ClipData, DecoderV2, EncoderV2
+from . import container
 
 psnr_f = lambda xa: 10 * math.log10(1. / xa)
 
@@ -104,6 +105,7 @@ class _EntropyModel(nn.Module):
         self.net = nn.Sequential(*layers)
         self.ext = DExtract2Batch(npart, ngroup, self.ctx2, device=gid)
         self.gmm = EntropyBatchGmmTable(bin_num, self.bias, 3, 65536, device=gid)
+        backend.watch_state_dict(self)  # reloaded weights drop the engine's repacked slabs
 
     def start(self, code_name='./tmp/data'):
         self.apply(restart_entropy_network)
@@ -176,10 +178,12 @@ class PseudoEncoder(nn.Module):
         self.ctx = PseudoContextV2(npart, opt, device=device_id)
         self.encoder = EncoderV2(CHANNELS, CHANNELS, npart, self.ctx, device_id).to(dev)
         self.quant = PseudoQUANTV2(CHANNELS, QUANT_LEVELS, npart, self.ctx, device_id=device_id, ntop=2)
+        self.valid_dim = valid_dim
         self.ext = Extract(valid_dim)
         self.mean_val = (QUANT_LEVELS - 1) / 2.
         self.dtw = Dtow(2, True, device_id)
         self.ent = EntEncoder(valid_dim // 4, npart, opt, QUANT_LEVELS, gid=device_id)
+        backend.watch_state_dict(self)
 
     def symbols(self, x):
         """quantiser indices in wavefront layout (npart, valid_dim/4, 2h, 2w)"""
@@ -187,21 +191,28 @@ class PseudoEncoder(nn.Module):
             _, code_i = self.quant(self.encoder(self.slice(x)))
             return self.dtw(self.ext(code_i))
 
-    def forward(self, x, code_name):
+    def forward(self, x, code_name, header=None):
         """x -> code file.  On the GPU the entropy stage runs on the native engine
         (engine.EntropyEngine: one launch per layer over all wavefront steps); the file is
         byte for byte what the op-by-op loop of `forward_per_op` writes
-        (tests/test_gpu_engine.py).  PCONV_ENTROPY=per-op forces the loop."""
+        (tests/test_gpu_engine.py).  PCONV_ENTROPY=per-op forces the loop.
+        header: dict(model_idx=, ssim=) -> the file gets the 16-byte container header
+        (container.py) in front of the same payload; None = the reference's raw stream."""
         with torch.no_grad():
             hcode_i = self.symbols(x)
             eng = _native_engine(self, "enc", hcode_i)
             if eng is None:
                 self.ent.start(code_name)
                 self.ent(hcode_i)
-                return
-            stream = eng.encode(self.ent.fill(hcode_i).contiguous())[0]
-            with open(code_name, "wb") as f:
-                f.write(stream)
+            else:
+                stream = eng.encode(self.ent.fill(hcode_i).contiguous())[0]
+                with open(code_name, "wb") as f:
+                    f.write(stream)
+            if header is not None:
+                with open(code_name, "rb") as f:
+                    payload = f.read()
+                container.write(code_name, payload, height=x.shape[2], width=x.shape[3],
+                                model_idx=header["model_idx"], ssim=header["ssim"], valid_dim=self.valid_dim)
 
     def forward_per_op(self, x, code_name):
         """the reference's loop (pseudo_codec.py:97-114): ~36 op calls per wavefront step"""
@@ -227,6 +238,7 @@ class PseudoDecoder(nn.Module):
         self.quant = PseudoDQUANT(self.code_channels, QUANT_LEVELS, self.npart, self.ctx, device_id=device_id)
         self.wtd = Dtow(2, False, device_id)
         self.ent = EntDecoder(self.valid_dim // 4, self.npart, opt, QUANT_LEVELS, gid=device_id)
+        backend.watch_state_dict(self)
 
     def reconstruct(self, hcode_i):
         """symbols in wavefront layout -> image"""
@@ -236,18 +248,35 @@ class PseudoDecoder(nn.Module):
             code_f[:, :self.valid_dim] = code_ext
             return self.clip(self.uslice(self.decoder(code_f.contiguous())))
 
-    def forward(self, code_name, height=512, width=1024):
+    def forward(self, code_name, height=512, width=1024, raw=True):
         """code file -> image; the entropy stage on the native engine when on the GPU
-        (see PseudoEncoder.forward)"""
+        (see PseudoEncoder.forward).  raw=False: the file carries the container header
+        (container.py) and height / width are read from it."""
         with torch.no_grad():
+            if not raw:
+                head, payload = container.read(code_name)
+                if head["valid_dim"] != self.valid_dim:
+                    raise container.ContainerError("file was coded with valid_dim %d, this decoder has %d"
+                                                   % (head["valid_dim"], self.valid_dim))
+                height, width = head["height"], head["width"]
             h, w = latent_shape(height, width, self.npart)
             eng = _native_engine(self, "dec", None, 2 * h, 2 * w)
             if eng is None:
+                if not raw:   # the coder modules read files: hand them the bare payload
+                    code_name = code_name + ".payload"
+                    with open(code_name, "wb") as f:
+                        f.write(payload)
                 self.ent.start(code_name)
-                return self.reconstruct(self.ent(2 * h, 2 * w))
-            with open(code_name, "rb") as f:
-                stream = f.read()
-            return self.reconstruct(eng.decode([stream]))
+                try:
+                    return self.reconstruct(self.ent(2 * h, 2 * w))
+                finally:
+                    if not raw:
+                        self.ent.mcoder = None
+                        os.remove(code_name)
+            if raw:
+                with open(code_name, "rb") as f:
+                    payload = f.read()
+            return self.reconstruct(eng.decode([payload]))
 
     def forward_per_op(self, code_name, height=512, width=1024):
         """the reference's loop (pseudo_codec.py:145-160)"""
@@ -326,24 +355,46 @@ def bitrate(path, height=512, width=1024):
     return os.path.getsize(path) * 8 / float(width) / float(height)
 
 
-def encoding(img_list, out_list, model_idx=0, mse=True, device_id=0, height=512, width=1024):
+def encoding(img_list, out_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, raw=False):
+    """raw=True writes the reference's headerless files; the default adds the 16-byte
+    container header so that the file decodes without any size / model argument"""
     prex, vd, model_dir = _pick(model_idx, mse)
     dev = backend.device_of(device_id)
     t1 = PseudoEncoder(vd, device_id=device_id).to(dev)
     load_models(t1, '{}/{}_encoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
+    header = None if raw else {"model_idx": model_idx, "ssim": not mse}
     for fn, fo in zip(img_list, out_list):
         data = img2tensor(check_img(read_image(fn), height, width), dev)
-        t1(data, fo)
+        t1(data, fo, header)
         print('Encoding {}, bitrate: {:.3f}bpp'.format(fn, bitrate(fo, height, width)))
 
 
-def decoding(code_list, decoded_img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024):
+def _decoder_for(code_list, model_idx, mse, device_id, raw):
+    """decoder with its checkpoint loaded; with container files the model is the one
+    the FIRST file names (all files of a call must agree)"""
+    if not raw:
+        head, _ = container.read(code_list[0])
+        model_idx, mse = head["model_idx"], not head["ssim"]
     prex, vd, model_dir = _pick(model_idx, mse)
     dev = backend.device_of(device_id)
     t1 = PseudoDecoder(vd, device_id=device_id).to(dev)
     load_models(t1, '{}/{}_decoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
+    return t1, dev, model_idx, mse
+
+
+def _check_same_model(fc, model_idx, mse):
+    head, _ = container.read(fc)
+    if head["model_idx"] != model_idx or head["ssim"] == mse:
+        raise container.ContainerError("%s was coded with another model than the first file of the list" % fc)
+    return head
+
+
+def decoding(code_list, decoded_img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, raw=False):
+    t1, dev, model_idx, mse = _decoder_for(code_list, model_idx, mse, device_id, raw)
     for fc, fo in zip(code_list, decoded_img_list):
-        write_image(fo, tensor2img(t1(fc, height, width)))
+        if not raw:
+            _check_same_model(fc, model_idx, mse)
+        write_image(fo, tensor2img(t1(fc, height, width, raw)))
         print('Decoding {}, output to {}'.format(fc, fo))
 
 
@@ -363,15 +414,15 @@ class ViewportMetrics(object):
         return psnr_f(mse_loss), self.sim_func(x, y).item()
 
 
-def decoding_and_test(code_list, img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024):
-    prex, vd, model_dir = _pick(model_idx, mse)
-    dev = backend.device_of(device_id)
-    t1 = PseudoDecoder(vd, device_id=device_id).to(dev)
-    load_models(t1, '{}/{}_decoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
+def decoding_and_test(code_list, img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, raw=False):
+    t1, dev, model_idx, mse = _decoder_for(code_list, model_idx, mse, device_id, raw)
     metrics = ViewportMetrics(device_id)
     rows = []
     for fc, fn in zip(code_list, img_list):
-        rdata = t1(fc, height, width)
+        if not raw:
+            head = _check_same_model(fc, model_idx, mse)
+            height, width = head["height"], head["width"]
+        rdata = t1(fc, height, width, raw)
         data = img2tensor(check_img(read_image(fn), height, width), dev)
         pr, vssim = metrics(data, rdata)
         rt = bitrate(fc, height, width)
@@ -411,6 +462,9 @@ def main(argv=None):
     parser.add_argument('--gpu-id', type=int, default=0, help='The graphic card id for encoding and decoding.')
     parser.add_argument('--height', type=int, default=512, help='ERP height of the coded image (multiple of 256)')
     parser.add_argument('--width', type=int, default=1024, help='ERP width of the coded image (multiple of 16)')
+    parser.add_argument('--raw', action='store_true', default=False,
+                        help="Headerless code files, the reference's format (size and model then come from the flags); "
+                             'default: files carry a 16-byte header (size, model, valid_dim, length)')
     args = parser.parse_args(argv)
     check_models()
     midx = args.model_idx
@@ -423,7 +477,7 @@ def main(argv=None):
     pick = lambda lst, fil: lst if lst is not None else (read_list(fil) if fil is not None else None)
     img_list, code_list, out_list = pick(args.img_list, args.img_file), pick(args.code_list, args.code_file), \
         pick(args.out_list, args.out_file)
-    size = dict(height=args.height, width=args.width)
+    size = dict(height=args.height, width=args.width, raw=args.raw)
     if args.enc:
         assert img_list is not None, 'No input images for encoding'
         assert code_list is not None, 'No code files for saving the codes'

@@ -1,0 +1,58 @@
+"""bench.py's own N > 1 path on the CPU: `python bench.py --gpus 2` must start two
+ranks (children, rendezvous on 127.0.0.1), every rank runs `bench.run`, and rank 0
+prints one JSON line with n_gpus == 2 and the SUM of both shards.  The ranks use
+gloo and a toy oracle workload (tests/helpers/bench_dryrun_rank.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "helpers", "bench_dryrun_rank.py")
+
+
+def _run(nproc, tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(%d, ['--gpus', '%d', '--steps', '2', '--warmup', '1', '--prime', '0', "
+            "'--frames-per-gpu', '2'], script=%r, env={'PCONV_DRYRUN_DIR': %r}))"
+            % (ROOT, nproc, nproc, WORKER, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1200)
+def test_launcher_starts_two_ranks_and_reduces(tmp_path):
+    two = _run(2, tmp_path)
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["frames_per_gpu"] == 2
+    # weak scaling: twice the pixels of one rank's shard in the same number of steps
+    pixels_per_rank_step = 2 * 256 * 1024
+    assert abs(two["value"] * 1e6 * two["ms_per_step"] * 1e-3 - 2 * pixels_per_rank_step) / (2 * pixels_per_rank_step) < 0.01
+    assert two["config"]["bpp"] > 0
+
+
+def test_main_becomes_launcher_only_without_world_size(monkeypatch):
+    """--gpus N with WORLD_SIZE set (the driver's torch.distributed.run) must NOT spawn again"""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, **kw: calls.append((n, list(argv))) or 0)
+    monkeypatch.setattr(bench, "run", lambda args, **kw: calls.append(("run", args.gpus)))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4", "--steps", "1"])
+    assert e.value.code == 0 and calls == [(4, ["--gpus", "4", "--steps", "1"])]
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.main(["--gpus", "4", "--steps", "1"])
+    assert calls == [("run", 4)]
+    calls.clear()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main(["--gpus", "1", "--steps", "1"])
+    assert calls == [("run", 1)]

@@ -32,6 +32,35 @@ def test_encode_decode_roundtrip_on_the_oracle(oracle_backend, tmp_path):
     assert torch.equal(out, enc.ent.fill(sym.clone()))          # (i) exact symbol round trip
     rec = dec(path, 256, 512)
     assert rec.shape == (1, 3, 256, 512) and torch.isfinite(rec).all()
+    # container file: 16-byte header + the SAME payload, decodes with no size arguments
+    from pseudocylindrical_convolution_amd import container
+    boxed = str(tmp_path / "code.pcv")
+    enc(x, boxed, {"model_idx": 3, "ssim": True})
+    head, payload = container.read(boxed)
+    with open(path, "rb") as f:
+        assert payload == f.read()
+    assert head == {"height": 256, "width": 512, "model_idx": 3, "ssim": True, "valid_dim": 56}
+    assert os.path.getsize(boxed) == os.path.getsize(path) + container.HEADER_BYTES
+    assert torch.equal(dec(boxed, raw=False), rec)
+    with pytest.raises(container.ContainerError):
+        dec(path, raw=False)                                       # a raw stream has no magic
+
+
+def test_container_header_fields_and_errors():
+    from pseudocylindrical_convolution_amd import container as C
+    blob = C.pack(b"\x01\x02\x03", height=2048, width=4096, model_idx=8, ssim=False, valid_dim=192)
+    assert len(blob) == 19 and blob[:4] == b"PCVC" and blob[4] == 1
+    head, payload = C.unpack(blob)
+    assert payload == b"\x01\x02\x03"
+    assert head == {"height": 2048, "width": 4096, "model_idx": 8, "ssim": False, "valid_dim": 192}
+    assert C.unpack(C.pack(b"", height=256, width=16, model_idx=0, ssim=True, valid_dim=56))[1] == b""
+    for bad in (blob[:10], b"XXXX" + blob[4:], blob + b"\x00", blob[:4] + b"\x07" + blob[5:]):
+        with pytest.raises(C.ContainerError):
+            C.unpack(bad)
+    with pytest.raises(C.ContainerError):
+        C.pack(b"", height=250, width=512, model_idx=0, ssim=True, valid_dim=56)
+    with pytest.raises(C.ContainerError):
+        C.pack(b"", height=256, width=512, model_idx=0, ssim=True, valid_dim=58)
 
 
 def test_state_dict_names_follow_the_reference(oracle_backend):
