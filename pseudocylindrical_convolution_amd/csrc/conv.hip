@@ -25,6 +25,7 @@
 // (the MFMA accumulates k0 then k1 into the same register, chunks continue the
 // chain), then + bias, then the activation.  The oracle restates exactly that.
 #include <atomic>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -90,15 +91,112 @@ struct ConvEpilogue {
   int d2w;  // depth-to-width x2 on the way out (DtowOp fused): out is (cout/4, 2*ho, 2*wo)
 };
 
-template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
-    const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
-    int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, ConvView vin,
-    ConvView vout, ConvEpilogue ep) {
+
+// a workgroup tile that lies entirely in dead columns: zeros (with the Dtow shuffle when fused)
+template <int BM, int ROWS, int THREADS>
+__device__ __forceinline__ void conv_zero_tile(float *outp, const ConvView &vout, int d2w, int cout0, int cout,
+                                               int r0, int c0, int ho, int wo, int tid) {
+  for (int e = tid; e < BM * ROWS * kTileCols; e += THREADS) {
+    const int col = e % kTileCols, row = (e / kTileCols) % ROWS, co = e / (kTileCols * ROWS);
+    if (cout0 + co < cout && r0 + row < ho && c0 + col < wo) {
+      const int cg = cout0 + co;
+      if (d2w)
+        outp[(size_t)(cg >> 2) * vout.cs + (size_t)(2 * (r0 + row) + ((cg >> 1) & 1)) * vout.rs +
+             2 * (c0 + col) + (cg & 1)] = 0.f;
+      else
+        outp[(size_t)cg * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
+    }
+  }
+}
+
+// The way out of the accumulators (see ConvEpilogue), shared by the tiled and the
+// weight-resident kernels.  Wave (wm, wn) holds MT x NT tiles of 32 couts x 32 pixels:
+// reg r of a tile = cout row (r&3) + 8*(r>>2) + 4*half, pixel column = l31; pixel
+// segment seg = wn*NT + n is row seg/2, 32-column half seg%2 of the workgroup tile.
+template <int MT, int NT, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvEpilogue &ep, const float *inp,
+                                              float *outp, const ConvView &vin, const ConvView &vout, int t, int r0,
+                                              int c0, int cout0, int cout, int ho, int wo, int wm, int wn, int l31,
+                                              int half) {
   const float *__restrict__ bias = ep.bias;
   const float *__restrict__ slope = ep.slope;
   const int32_t *__restrict__ col_limit = ep.col_limit;
   const int npart = ep.npart, act = ep.act;
+  const int trim_at = ((ep.trim || act == 2 || act == 3) && col_limit) ? col_limit[t % npart] : wo;
+  const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+  const float *gatep = ep.gate ? ep.gate + (size_t)t * ep.vgate.ts : nullptr;
+  // epilogue (see ConvEpilogue).  reg r of a 32x32 tile: cout row
+  // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
+  if (ep.d2w) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int rp = 0; rp < 8; rp++) {
+        const int r = 2 * rp;  // registers r, r+1: couts co (even), co+1 = sx 0, 1
+        const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= cout) continue;
+        const float b0 = bias ? bias[co] : 0.f, b1 = bias ? bias[co + 1] : 0.f;
+        const float s0 = (act == 1) ? slope[co] : 0.f, s1 = (act == 1) ? slope[co + 1] : 0.f;
+        const int cq = co >> 2, sy = (co >> 1) & 1;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int seg = wn * NT + n;
+          const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+          if (orow < ho && ocol < wo) {
+            float2 v = make_float2(acc[m][n][r] + b0, acc[m][n][r + 1] + b1);
+            if (act == 1) {
+              if (v.x < 0) v.x = v.x * s0;
+              if (v.y < 0) v.y = v.y * s1;
+            }
+            *reinterpret_cast<float2 *>(outp + (size_t)cq * vout.cs + (size_t)(2 * orow + sy) * vout.rs + 2 * ocol) = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= cout) continue;
+      const float bco = bias ? bias[co] : 0.f;
+      const float sl = (act == 1) ? slope[co] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const int seg = wn * NT + n;
+        const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+        if (orow < ho && ocol < wo) {
+          const size_t oi = (size_t)co * vout.cs + (size_t)orow * vout.rs + ocol;
+          float v = acc[m][n][r] + bco;
+          if (act == 1) {
+            if (v < 0) v = v * sl;
+          } else if (act == 2 || act == 3) {
+            // 1x1, stride 1: input and output share their geometry
+            const float xv = inp[(size_t)co * vin.cs + (size_t)orow * vin.rs + ocol];
+            const float nrm = sqrtf(v);
+            v = act == 2 ? xv / nrm : xv * nrm;
+          } else if (act == 4) {
+            v = 1.f / (1.f + expf(-v));
+          }
+          if (gatep) v = gatep[(size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + ocol] * v;
+          if (resp) v = resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol] + v;
+          if (ocol >= trim_at) v = 0.f;
+          outp[oi] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
+    const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
+    int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, int xcd_group, ConvView vin,
+    ConvView vout, ConvEpilogue ep) {
+  const int32_t *__restrict__ col_limit = ep.col_limit;
+  const int npart = ep.npart;
   using C = ConvCfg<MT, NT, WM, WN, KS, S, KC>;
   using P = typename C::P;
   constexpr int kThreads = C::THREADS;
@@ -112,6 +210,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
   // ones all landed on the same engines and the live engines set the time
   // (measured: 50 % dead workgroups, 0 % less time).
   int b = blockIdx.x;
+  if (xcd_group > 0) {
+    // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8, observed; used
+    // for speed only).  Row-neighbour workgroups share input rows, so one column stripe
+    // (xcd_group = cblocks * tiles_r consecutive logical blocks) is given to ONE XCD and
+    // its shared rows are fetched into one L2 once; consecutive stripes rotate over the
+    // XCDs, which also spreads the dead stripes (they depend on the column tile only).
+    const int full = (int)(gridDim.x / (8u * xcd_group)) * 8 * xcd_group;
+    if (b < full) {
+      const int x = b & 7, j = b >> 3;
+      b = (j / xcd_group) * 8 * xcd_group + x * xcd_group + j % xcd_group;
+    }
+  }
   const int cb = b % cblocks;
   b /= cblocks;
   const int trx = b % tiles_r;
@@ -131,17 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
 
   if (col_limit && c0 >= col_limit[t % npart]) {
     // tile lies entirely in the dead columns of this latitude band: zeros
-    for (int e = tid; e < C::BM * kTileRows * kTileCols; e += kThreads) {
-      const int col = e % kTileCols, row = (e / kTileCols) % kTileRows, co = e / (kTileCols * kTileRows);
-      if (cout0 + co < cout && r0 + row < ho && c0 + col < wo) {
-        const int cg = cout0 + co;
-        if (ep.d2w)
-          outp[(size_t)(cg >> 2) * vout.cs + (size_t)(2 * (r0 + row) + ((cg >> 1) & 1)) * vout.rs +
-               2 * (c0 + col) + (cg & 1)] = 0.f;
-        else
-          outp[(size_t)cg * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
-      }
-    }
+    conv_zero_tile<C::BM, kTileRows, kThreads>(outp, vout, ep.d2w, cout0, cout, r0, c0, ho, wo, tid);
     return;
   }
 
@@ -281,72 +381,171 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     __syncthreads();
   }
 
-  const int trim_at = ((ep.trim || act == 2 || act == 3) && col_limit) ? col_limit[t % npart] : wo;
-  const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
-  const float *gatep = ep.gate ? ep.gate + (size_t)t * ep.vgate.ts : nullptr;
-  // epilogue (see ConvEpilogue).  reg r of a 32x32 tile: cout row
-  // (r&3) + 8*(r>>2) + 4*half, pixel column = l31.
-  if (ep.d2w) {
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-#pragma unroll
-      for (int rp = 0; rp < 8; rp++) {
-        const int r = 2 * rp;  // registers r, r+1: couts co (even), co+1 = sx 0, 1
-        const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= cout) continue;
-        const float b0 = bias ? bias[co] : 0.f, b1 = bias ? bias[co + 1] : 0.f;
-        const float s0 = (act == 1) ? slope[co] : 0.f, s1 = (act == 1) ? slope[co + 1] : 0.f;
-        const int cq = co >> 2, sy = (co >> 1) & 1;
-#pragma unroll
-        for (int n = 0; n < NT; n++) {
-          const int seg = wn * NT + n;
-          const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
-          if (orow < ho && ocol < wo) {
-            float2 v = make_float2(acc[m][n][r] + b0, acc[m][n][r + 1] + b1);
-            if (act == 1) {
-              if (v.x < 0) v.x = v.x * s0;
-              if (v.y < 0) v.y = v.y * s1;
-            }
-            *reinterpret_cast<float2 *>(outp + (size_t)cq * vout.cs + (size_t)(2 * orow + sy) * vout.rs + 2 * ocol) = v;
-          }
-        }
-      }
+  conv_epilogue<MT, NT, WN>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half);
+}
+
+// ---- weight-resident 1x1 convolution ------------------------------------------------
+// The 1x1 layers (ResidualBlock conv1 / conv3, the attention gate, the shortcuts, and
+// the GDN contraction) have K = cin <= 192: per 16-channel chunk the tiled kernel above
+// does only 8 k-pairs of matrix work between two barriers, less than the LDS-DMA of the
+// next chunk needs to land (measured: matrix pipes 20-45 % busy, 0.14-0.27 of the
+// roof).  Here the WHOLE [K][BM] weight slab of the workgroup's cout block is staged in
+// LDS once (up to 144 KB: one workgroup per CU for BM = 192, two for BM = 96) and the
+// reduction loop has no barrier at all: a wave owns BM couts x 32 pixels, takes its A
+// operands from the slab and its B operands -- 32 consecutive pixels of channel 2kp
+// (lanes 0-31) and 2kp+1 (lanes 32-63), a coalesced 2 x 128-byte load -- straight from
+// global memory through an 8-deep register ring ("scalar base + lane offset" loads, the
+// base advances by two channels per k-pair).  A workgroup walks `passes` row groups of
+// ROWS = WN/2 rows x 64 columns with the same slab.  Same MFMA sequence per output as
+// the tiled kernel (k ascending from 0), same epilogue: the results are bit-identical.
+typedef const __attribute__((address_space(1))) char global_bytes;  // (a global, not a flat, access)
+__device__ __forceinline__ float load_base_off(global_bytes *base, unsigned off) {
+  asm volatile("" : "+v"(off));  // keeps the 32-bit lane offset out of a hoisted 64-bit add
+  return *reinterpret_cast<const __attribute__((address_space(1))) float *>(base + off);
+}
+
+template <int MT, int WN, bool SQ>
+__global__ __launch_bounds__(64 * WN, MT <= 3 ? 4 : 2) void conv1x1_resident_kernel(
+    const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int kpad, int h, int w,
+    int cout, int cout_pad, int tiles_r, int tiles_c, int cblocks, int passes, ConvView vin, ConvView vout,
+    ConvEpilogue ep) {
+  constexpr int kThreads = 64 * WN, BM = 32 * MT, ROWS = WN / 2, D = 8;
+  extern __shared__ float lds[];  // ws[kpad][BM]
+  int b = blockIdx.x;
+  const int cb = b % cblocks;
+  b /= cblocks;
+  const int trx = b % tiles_r;
+  b /= tiles_r;
+  const int tcx = b % tiles_c;
+  const int t = b / tiles_c;
+  const int c0 = tcx * kTileCols, cout0 = cb * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  float *outp = out + (size_t)t * vout.ts;
+  const float *inp = in + (size_t)t * vin.ts;
+  const int ho = h, wo = w;
+  if (ep.col_limit && c0 >= ep.col_limit[t % ep.npart]) {
+    for (int pass = 0; pass < passes; pass++) {
+      const int r0 = (trx * passes + pass) * ROWS;
+      if (r0 < ho) conv_zero_tile<BM, ROWS, kThreads>(outp, vout, ep.d2w, cout0, cout, r0, c0, ho, wo, tid);
     }
     return;
   }
-#pragma unroll
-  for (int m = 0; m < MT; m++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= cout) continue;
-      const float bco = bias ? bias[co] : 0.f;
-      const float sl = (act == 1) ? slope[co] : 0.f;
-#pragma unroll
-      for (int n = 0; n < NT; n++) {
-        const int seg = wn * NT + n;
-        const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
-        if (orow < ho && ocol < wo) {
-          const size_t oi = (size_t)co * vout.cs + (size_t)orow * vout.rs + ocol;
-          float v = acc[m][n][r] + bco;
-          if (act == 1) {
-            if (v < 0) v = v * sl;
-          } else if (act == 2 || act == 3) {
-            // 1x1, stride 1: input and output share their geometry
-            const float xv = inp[(size_t)co * vin.cs + (size_t)orow * vin.rs + ocol];
-            const float nrm = sqrtf(v);
-            v = act == 2 ? xv / nrm : xv * nrm;
-          } else if (act == 4) {
-            v = 1.f / (1.f + expf(-v));
-          }
-          if (gatep) v = gatep[(size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + ocol] * v;
-          if (resp) v = resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol] + v;
-          if (ocol >= trim_at) v = 0.f;
-          outp[oi] = v;
-        }
-      }
+  {
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    const int n4 = kpad * BM / 4;
+    for (int e4 = tid; e4 < n4; e4 += kThreads) {
+      const int kk = e4 / (BM / 4), co = (e4 % (BM / 4)) * 4;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wp + (size_t)kk * cout_pad + cout0 + co),
+                                       (lds_ptr_t *)(lds + (size_t)(e4 - lane) * 4), 16, 0, 0);
     }
   }
+  __syncthreads();  // (waits for the DMA: vmcnt(0))
+  const int KP = kpad / 2;
+  const size_t kstep = (size_t)2 * vin.cs * sizeof(float);
+  const float *wsl = lds + half * BM + l31;
+#pragma unroll 1
+  for (int pass = 0; pass < passes; pass++) {
+    const int r0 = (trx * passes + pass) * ROWS;
+    if (r0 >= ho) break;
+    int ir = r0 + (wn >> 1), ic = c0 + (wn & 1) * 32 + l31;
+    ir = ir < h ? ir : h - 1;
+    ic = ic < w ? ic : w - 1;
+    const unsigned loff = (unsigned)(((long long)half * vin.cs + (long long)ir * vin.rs + ic) * sizeof(float));
+    // wave-uniform base in scalar registers: the loads are "SGPR base + lane offset"
+    const unsigned long long in_u = reinterpret_cast<unsigned long long>(inp);
+    global_bytes *bbase = reinterpret_cast<global_bytes *>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(in_u >> 32)) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)in_u));  // (int result: no sign extension)
+    f32x16 acc[MT][1];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][0][r] = 0.f;
+    float bq[D], a[2][MT];
+#pragma unroll
+    for (int j = 0; j < D; j++) bq[j] = load_base_off(bbase + j * kstep, loff);
+#pragma unroll
+    for (int m = 0; m < MT; m++) a[0][m] = wsl[m * 32];
+#pragma unroll 1
+    for (int kp0 = 0; kp0 < KP; kp0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; j++) {
+        const int kp = kp0 + j;
+        float bv = bq[j];
+        // the ring always refills (past the end: the last k-pair again, never used) and the
+        // next A fragment is always read: no branches inside the matrix loop
+        const int kpre = kp + D < KP ? kp + D : KP - 1;
+        bq[j] = load_base_off(bbase + (size_t)kpre * kstep, loff);
+        const int knext = kp + 1 < KP ? kp + 1 : KP - 1;
+#pragma unroll
+        for (int m = 0; m < MT; m++) a[(j + 1) & 1][m] = wsl[(size_t)knext * 2 * BM + m * 32];
+        if (SQ) bv = bv * bv;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][m], bv, acc[m][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // (cout0 made opaque per pass: otherwise the per-channel bias / slope loads of the
+    // epilogue are hoisted out of the pass loop and live -- 2 x BM of them -- across the
+    // matrix loop, which spills)
+    int cout0_pass = __builtin_amdgcn_readfirstlane(cout0);
+    asm volatile("" : "+s"(cout0_pass));
+    conv_epilogue<MT, 1, WN>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0_pass, cout, ho, wo, 0, wn, l31, half);
+  }
+}
+
+template <int MT, int WN, bool SQ>
+int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout,
+                   int cout_pad, const ConvView &vin, const ConvView &vout, const ConvEpilogue &ep,
+                   hipStream_t stream) {
+  constexpr int BM = 32 * MT, ROWS = WN / 2;
+  const int kpad = (cin + 15) / 16 * 16;
+  const int tiles_c = (w + kTileCols - 1) / kTileCols;
+  const int cblocks = (cout + BM - 1) / BM;
+  // two row groups per workgroup (the slab is staged once for both) while that still
+  // leaves >= 4 workgroups per CU-slot
+  const long long single = (long long)tn * ((h + ROWS - 1) / ROWS) * tiles_c * cblocks;
+  const int passes = single >= 2048 ? 2 : 1;
+  const int tiles_r = (h + ROWS * passes - 1) / (ROWS * passes);
+  const long long grid = (long long)tn * tiles_r * tiles_c * cblocks;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    pconv_set_error("conv2d: grid %lld out of range", grid);
+    return PCONV_EINVAL;
+  }
+  const size_t smem = (size_t)kpad * BM * sizeof(float);
+  auto kern = conv1x1_resident_kernel<MT, WN, SQ>;
+  if (smem > 64 * 1024) {
+    static std::atomic<unsigned long long> raised{0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+    const unsigned long long bit = 1ULL << (device & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) {
+        pconv_set_error("conv2d: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e));
+        return PCONV_ELAUNCH;
+      }
+      raised.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WN), smem, stream, in, wp, out, kpad, h, w, cout,
+                     cout_pad, tiles_r, tiles_c, cblocks, passes, vin, vout, ep);
+  return PCONV_OK;
+}
+
+// the weight-resident form takes 1x1 stride-1 layers whose slab fits LDS
+// (PCONV_CONV1X1=tiled forces the tiled kernel: A/B measurements and the parity tests)
+inline bool use_resident_1x1(int cin, int cout) {
+  const char *env = getenv("PCONV_CONV1X1");
+  if (env && env[0] == 't') return false;
+  const int kpad = (cin + 15) / 16 * 16;
+  const int bm = cout > 96 ? 192 : 96;
+  return cin >= 32 && cin % 16 == 0 && cout > 32 && (size_t)kpad * bm * sizeof(float) <= 150 * 1024;
 }
 
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded
@@ -393,8 +592,11 @@ int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, i
       raised.fetch_or(bit, std::memory_order_release);
     }
   }
+  // PCONV_CONV_XCD=0 keeps the plain order (A/B measurements)
+  static const bool xcd_order = !(getenv("PCONV_CONV_XCD") && atoi(getenv("PCONV_CONV_XCD")) == 0);
+  const int xcd_group = (xcd_order && KS == 3) ? cblocks * tiles_r : 0;  // 1x1 tiles share no rows
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, out, cin, h, w, cout,
-                     cout_pad, ho, wo, tiles_r, tiles_c, cblocks, vin, vout, ep);
+                     cout_pad, ho, wo, tiles_r, tiles_c, cblocks, xcd_group, vin, vout, ep);
   return PCONV_OK;
 }
 
@@ -483,6 +685,11 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
     BY_TILE(3, 1, 4)
   } else if (k == 3 && stride == 2) {
     BY_TILE(3, 2, 4)
+  } else if (k == 1 && stride == 1 && use_resident_1x1(cin, cout)) {
+    if (cout > 96)
+      rc = launch_conv1x1<6, 8, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+    else
+      rc = launch_conv1x1<3, 8, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
   } else if (k == 1 && stride == 1) {
     BY_TILE(1, 1, 16)
   } else {
@@ -516,7 +723,11 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
   PCONV_REQUIRE(view_ok(vin, ch, h, w) && view_ok(vout, ch, h, w) && (!residual || view_ok(ep.vres, ch, h, w)),
                 "gdn: strides overlap");
   int rc;
-  if (ch > 96)
+  if (use_resident_1x1(ch, ch) && ch > 96)
+    rc = launch_conv1x1<6, 8, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  else if (use_resident_1x1(ch, ch))
+    rc = launch_conv1x1<3, 8, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  else if (ch > 96)
     rc = launch_conv<3, 1, 2, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)
     rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);

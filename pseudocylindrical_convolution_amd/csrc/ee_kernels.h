@@ -16,26 +16,57 @@
 #pragma once
 #include <stdint.h>
 
+// One record per schedule entry (wavefront position), built once on the host: what a
+// step kernel needs to find a position's window, output and halos without integer
+// divisions (the scalar unit, one per CU, was the busiest resource of the step kernels).
+struct EePos {
+  int32_t pix;   // (tile*(h+4) + row)*(w+4) + col: origin of the 5 x 5 window in a buffer padded by 2;
+                 // the position itself sits at pix + 2*(w+4) + 2 in such a buffer
+  int32_t hw;    // (tile*h + row)*w + col: index in an unpadded buffer (= the schedule value)
+  int32_t wrap;  // col < 2: valid width of the tile (the value is also stored `wrap` columns to the
+                 // right, the circular wrap of the first columns); else 0
+  int32_t rev;   // first reverse-halo record << 4 | count (rows that feed halos of neighbouring tiles)
+};
+
+// One record per (producing position, halo entry interpolated from it): the entry equals
+// a*t + b*(1-t) of its two source columns, one of which is the producer.
+struct EeHalo {
+  int32_t dst;    // padded pixel index of the halo entry
+  int32_t other;  // padded pixel index of the source that is NOT the producer (-1: none, reads as 0)
+  float t;
+  int32_t info;   // bits 0-15: wrap delta in columns (entry column < 2: also stored there), bit 30: the
+                  // producer is the second source (b), bit 29: both sources are the producer
+};
+
 struct EeGeom {
   int npart, ngroup, h, w;  // tiles, channel groups, rows per tile, columns
   int nimg;                 // frames in lock-step (the network runs 3*nimg replicas)
   const int32_t *widths;    // device, valid width per tile
   const int32_t *order, *plane_start;  // device, wavefront schedule
-  const int32_t *vh_col;    // device, dense causal halo table
+  const int32_t *vh_col;    // device, dense causal halo table (bulk halo pass)
   const float *vh_wgt;
-  // device, CSR over (global row*w + col): halo entries (indices into vh_col) that
-  // read this interior column as one of their two sources
-  const int32_t *rev_start, *rev_entry;
+  const EePos *pos;         // device, one record per schedule entry
+  const EeHalo *halo;       // device, reverse halo records (EePos::rev indexes them)
+  const uint32_t *tap_in, *tap_hid;  // device, byte offset of reduction entry kk inside a window of the
+                                     // context (ngroup channels) / of a hidden layer (3*ngroup), 0 past the end
   // bulk (encoder) mode: every (plane, group) pair at once
   const int32_t *pos_plane;  // device, plane of every schedule entry
   const int32_t *step_row;   // device, first table row of every step (rows are [step][img][l])
   int npos;
 };
 
-// weights (3, cout, cin, 5, 5) -> per (set, output group) a slab [tap*cin + ci][4]
-// with the group's 3 rows interleaved (entropy_engine.hip)
-static inline size_t ee_packed_floats(int nset, int cout, int cin) { return (size_t)nset * (cout / 3) * cin * 25 * 4; }
-int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, void *stream);
+// reduction entries of a slab, padded to whole waves
+static inline int ee_slab_slots(int cin) { return (cin * 25 + 63) / 64 * 64; }
+// weights (3, cout, cin, 5, 5) -> per (set, output group) a slab [slot][4], slot = tap*cin + ci,
+// holding the group's 3 rows interleaved (4th float: padding) with the CAUSAL MASK of the
+// group applied (masked taps and the slots past the reduction length are zeros): tap (kh, kw)
+// of input channel ci is usable by output group tc iff ci < (tc + slack + 4 - kh - kw)*(cin/ngroup),
+// slack = 0 for the input layer (constrain 5), 1 for the hidden ones (constrain 6)
+static inline size_t ee_packed_floats(int nset, int cout, int cin) {
+  return (size_t)nset * (cout / 3) * ee_slab_slots(cin) * 4;
+}
+int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
+                   void *stream);
 
 // one layer of one step.  x: cin channels, padded by 2; y: cout channels, padded
 // by pad_out.  shared_input: x holds nimg images that every replica reads

@@ -175,7 +175,9 @@ struct pconv_entropy_engine {
   int rows, nsteps, longest_plane = 0;
   std::vector<int32_t> widths, sched_start;
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
-  int32_t *rev_start_d = nullptr, *rev_entry_d = nullptr;
+  EePos *pos_d = nullptr;
+  EeHalo *halo_d = nullptr;
+  uint32_t *tap_in_d = nullptr, *tap_hid_d = nullptr;
   float *vh_wgt = nullptr;
   int32_t *pos_plane_d = nullptr;
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
@@ -261,8 +263,10 @@ struct pconv_entropy_engine {
       // reverse map: interior (global row, column) -> halo entries interpolated from it
       // (entry en = ((tile*2 + side)*kPad + r)*w + column reads source columns c and
       // c+1, circular, of the neighbouring tile's row; entry columns past the tile's
-      // valid width are never read and stay out)
-      std::vector<std::vector<int32_t>> lists((size_t)rows * w);
+      // valid width are never read and stay out).  One EeHalo record per (source, entry).
+      const int win = w + 2 * kPad, hp = h + 2 * kPad;
+      auto padded = [&](int tile, int prow, int pcol) { return (int32_t)((tile * hp + prow) * win + pcol); };
+      std::vector<std::vector<EeHalo>> lists((size_t)rows * w);
       for (size_t en = 0; en < n; en++) {
         const int cp = (int)(en % w);
         size_t q = en / w;
@@ -273,25 +277,74 @@ struct pconv_entropy_engine {
         if (c == -2 || cp >= widths[tg]) continue;
         const int srow = side ? (tg + 1) * h + r : tg * h - kPad + r;
         if (srow < 0 || srow >= rows) continue;
-        const int wst = widths[srow / h];
+        const int st = srow / h, sr = srow - st * h;
+        const int wst = widths[st];
         int c1 = c + 1;
         c1 = c1 >= wst ? c1 - wst : c1;
-        if (c >= 0) lists[(size_t)srow * w + c].push_back((int32_t)en);
-        if (c1 != c) lists[(size_t)srow * w + c1].push_back((int32_t)en);
+        EeHalo rec;
+        rec.dst = padded(tg, side ? h + kPad + r : r, cp + kPad);
+        rec.t = wg[en];
+        const int wrap = cp < kPad ? widths[tg] : 0;
+        const int32_t pa = c >= 0 ? padded(st, sr + kPad, c + kPad) : -1;
+        const int32_t pb = padded(st, sr + kPad, c1 + kPad);
+        if (c >= 0) {  // the producer is source a; the other one is b (or a itself when c1 == c)
+          rec.other = pb;
+          rec.info = wrap | (c1 == c ? (1 << 29) : 0);
+          lists[(size_t)srow * w + c].push_back(rec);
+        }
+        if (c1 != c) {  // the producer is source b
+          rec.other = pa;
+          rec.info = wrap | (1 << 30);
+          lists[(size_t)srow * w + c1].push_back(rec);
+        }
       }
-      std::vector<int32_t> rstart(lists.size() + 1, 0), rentry;
+      std::vector<int32_t> rstart(lists.size() + 1, 0);
+      std::vector<EeHalo> recs;
       for (size_t k = 0; k < lists.size(); k++) {
-        rentry.insert(rentry.end(), lists[k].begin(), lists[k].end());
-        rstart[k + 1] = (int32_t)rentry.size();
+        if (lists[k].size() > 15) {
+          pconv_set_error("ee_create: %zu halo entries hang on one position (record format holds 15)", lists[k].size());
+          return PCONV_EINVAL;
+        }
+        recs.insert(recs.end(), lists[k].begin(), lists[k].end());
+        rstart[k + 1] = (int32_t)recs.size();
       }
-      if (rentry.empty()) rentry.push_back(0);
-      HIP_TRY(hipMalloc(&rev_start_d, rstart.size() * 4));
-      HIP_TRY(hipMalloc(&rev_entry_d, rentry.size() * 4));
-      HIP_TRY(hipMemcpy(rev_start_d, rstart.data(), rstart.size() * 4, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(rev_entry_d, rentry.data(), rentry.size() * 4, hipMemcpyHostToDevice));
+      if (recs.size() >= (1u << 27)) {
+        pconv_set_error("ee_create: too many halo records");
+        return PCONV_EINVAL;
+      }
+      if (recs.empty()) recs.push_back(EeHalo{0, -1, 0.f, 0});
+      HIP_TRY(hipMalloc(&halo_d, recs.size() * sizeof(EeHalo)));
+      HIP_TRY(hipMemcpy(halo_d, recs.data(), recs.size() * sizeof(EeHalo), hipMemcpyHostToDevice));
+      // one EePos record per schedule entry
+      const int npos = sched_start[rows + w - 1];
+      std::vector<EePos> pos(npos);
+      for (int i = 0; i < npos; i++) {
+        const int hw = order[i], tw = hw % w, row = hw / w, tg = row / h, th = row - tg * h;
+        EePos p;
+        p.pix = padded(tg, th, tw);
+        p.hw = hw;
+        p.wrap = tw < kPad ? widths[tg] : 0;
+        const int cnt = (th < kPad || th >= h - kPad) ? rstart[(size_t)row * w + tw + 1] - rstart[(size_t)row * w + tw] : 0;
+        p.rev = (rstart[(size_t)row * w + tw] << 4) | cnt;
+        pos[i] = p;
+      }
+      HIP_TRY(hipMalloc(&pos_d, pos.size() * sizeof(EePos)));
+      HIP_TRY(hipMemcpy(pos_d, pos.data(), pos.size() * sizeof(EePos), hipMemcpyHostToDevice));
+      // byte offset of reduction entry kk = tap*cin + ci inside a 5 x 5 x cin window
+      for (int pass = 0; pass < 2; pass++) {
+        const int cin = pass == 0 ? ngroup : 3 * ngroup;
+        std::vector<uint32_t> tap(ee_slab_slots(cin), 0u);
+        for (int kk = 0; kk < cin * 25; kk++) {
+          const int t5 = kk / cin, ci = kk - t5 * cin;
+          tap[kk] = 4u * (uint32_t)(((t5 / 5) * win + t5 % 5) * cin + ci);
+        }
+        uint32_t **dst = pass == 0 ? &tap_in_d : &tap_hid_d;
+        HIP_TRY(hipMalloc(dst, tap.size() * 4));
+        HIP_TRY(hipMemcpy(*dst, tap.data(), tap.size() * 4, hipMemcpyHostToDevice));
+      }
     }
-    EeGeom base = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, rev_start_d,
-                   rev_entry_d, nullptr, nullptr, 0};
+    EeGeom base = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, pos_d,
+                   halo_d, tap_in_d, tap_hid_d, nullptr, nullptr, 0};
     {  // bulk (encoder) maps
       const int npos = sched_start[rows + w - 1];
       std::vector<int32_t> pp(npos);
@@ -328,7 +381,7 @@ struct pconv_entropy_engine {
       if (p) (void)hipFree(p);
     };
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
-    freed(pos_plane_d); freed(rev_start_d); freed(rev_entry_d);
+    freed(pos_plane_d); freed(pos_d); freed(halo_d); freed(tap_in_d); freed(tap_hid_d);
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
     for (Group &g : groups) {
       freed(g.ctx); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
@@ -498,7 +551,8 @@ void pconv_ee_destroy(pconv_entropy_engine *e) {
 int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, const float *bias,
                        const float *slope, void *stream) {
   PCONV_REQUIRE(e && layer >= 0 && layer < kLayers && weight && bias, "ee_set_layer: bad argument");
-  PC_TRY(ee_pack_weight(weight, e->lw[layer], 3, 3 * e->ngroup, e->layer_cin(layer), stream));
+  PC_TRY(ee_pack_weight(weight, e->lw[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, layer == 0 ? 5 : 6,
+                        stream));
   e->lb[layer] = bias;
   e->la[layer] = slope;
   e->bound[layer] = true;

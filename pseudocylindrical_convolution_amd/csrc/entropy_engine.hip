@@ -12,6 +12,7 @@
 // EntropyCtxPadRun2 stores in the per-op path, one launch per layer per step) is
 // applied in the epilogue of the kernel that computes the value, so consumers
 // read plain padded windows.
+#include <stdlib.h>
 #include "common.h"
 #include "ee_kernels.h"
 #include "gmm_device.h"
@@ -121,17 +122,26 @@ __device__ __forceinline__ float butterfly12(const float (&v)[4][GO], int lane) 
   return t;
 }
 
-// Packed weights: for every (set, output group) one slab [kk][4] holding the GO = 3
-// rows of the group interleaved (4th float is padding), kk = tap*cin + ci.  A lane
-// then fetches its three weights of a tap with one 16-byte LDS read.
-__host__ __device__ constexpr int slab_floats(int cin) { return cin * KK * 4; }
+// Packed weights: for every (set, output group) one slab [slot][4] holding the GO = 3
+// rows of the group interleaved (4th float is padding), slot = tap*cin + ci, padded to
+// whole waves, with the causal mask of the output group already applied (see
+// ee_kernels.h).  A lane fetches its three weights of a tap with one 16-byte LDS read and
+// a masked tap contributes fmaf(x, 0, acc) == acc (x is finite).
+__host__ __device__ constexpr int slab_slots(int cin) { return (cin * KK + kWave - 1) / kWave * kWave; }
+__host__ __device__ constexpr int slab_floats(int cin) { return slab_slots(cin) * 4; }
 
-__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ packed, int cin, int total) {
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ packed, int cin, int ngroup,
+                                   int slack, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int red = cin * KK;
-  const int o = i & 3, kk = (i >> 2) % red, grp = (i >> 2) / red;  // grp = set*ngroup + tc
-  packed[i] = o < GO ? w[((size_t)grp * GO + o) * red + (kk % cin) * KK + kk / cin] : 0.f;
+  const int red = cin * KK, slots = (red + kWave - 1) / kWave * kWave;
+  const int o = i & 3, kk = (i >> 2) % slots, grp = (i >> 2) / slots;  // grp = set*ngroup + tc
+  const int tc = grp % ngroup, group_in = cin / ngroup;
+  const int tap = kk / cin, ci = kk - tap * cin;
+  const int kh = tap / K, kw = tap - kh * K;
+  // causality: input group gi at window offset (kh, kw) is usable iff gi + kh + kw - 4 < tc + slack
+  const bool ok = kk < red && o < GO && (2 * HALF - kh - kw) * group_in - ci + (tc + slack) * group_in > 0;
+  packed[i] = ok ? w[((size_t)grp * GO + o) * red + ci * KK + tap] : 0.f;
 }
 
 // Walks the reduction index kk = lane, lane + 64, ... and keeps its decomposition
@@ -241,6 +251,7 @@ __global__ void ee_halo_bulk_kernel(EeGeom g, float *__restrict__ buf, int C, lo
 
 // ---- layers --------------------------------------------------------------
 
+// copies a (pre-masked, padded) slab to LDS
 template <int CIN, int BLOCK>
 __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict__ wrow, int tid) {
   constexpr int N4 = slab_floats(CIN) / 4;
@@ -249,102 +260,52 @@ __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict
   for (int i = tid; i < N4; i += BLOCK) dst[i] = src[i];
 }
 
-// the same with the causal mask of output group tc applied: masked taps are staged
-// as zeros (fmaf(x, 0, acc) == acc for finite x), so the consumers need no test
-template <int CIN, int BLOCK>
-__device__ __forceinline__ void stage_weights_masked(float *wl, const float *__restrict__ wrow, int tid,
-                                                     int group_in, int causal_base) {
-  constexpr int N4 = slab_floats(CIN) / 4;
-  const float4 *src = reinterpret_cast<const float4 *>(wrow);
-  float4 *dst = reinterpret_cast<float4 *>(wl);
-  for (int kk = tid; kk < N4; kk += BLOCK) {
-    const int tap = kk / CIN, ci = kk - tap * CIN;
-    const int kh = tap / K, kw = tap - kh * K;
-    const bool ok = (2 * HALF - kh - kw) * group_in - ci + causal_base > 0;
-    dst[kk] = ok ? src[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-
-// Step form: grid = 3 weight sets x planes of the step's window x images x `split`.
-// All positions of a plane share the output group, so the (set, group) weight slab
-// is fetched ONCE per workgroup, causally masked taps as zeros, together with the
-// window offsets of the taps; the waves then walk the plane's position list with
-// stride split*waves: per position 17 gathers from one scalar base (42 input
-// channels), 51 fmaf, the butterfly, the epilogue.  The launch is latency-bound
-// (a wave's positions form a chain of memory round trips), so what matters is how
-// many waves are resident:
-//   WLDS  the slab lives in LDS (float4 per tap + a dword offset array, 21 KB per
-//         workgroup) and a lane keeps only its 17 window values: ~64 registers,
-//         8 waves per SIMD;
-//   else  each lane holds its taps' weights and offsets in registers (5 per tap):
-//         for wide layers whose slab does not fit LDS several times per CU.
-template <int CIN, int ITER, int BLOCK, bool WLDS>
-__global__ __launch_bounds__(BLOCK, WLDS ? 8 : waves_per_eu(ITER)) void ee_conv_kernel(
+// Step form: grid = (parts, planes of the step's window, 3 weight sets x images).  All
+// positions of a plane share the output group, so the workgroup stages the (set, group)
+// slab ONCE, by LDS-DMA (no staging registers, no VALU); a lane keeps the byte offsets
+// of its ITER taps inside a window in registers (a table: they depend on the layer type
+// only) and the waves then walk the plane's position list with stride parts*waves.  Per
+// position: one 16-byte scalar load of its record (the next one is requested before the
+// current one is used), ITER gathers from one scalar base, 3*ITER fmaf against the LDS
+// slab, the packed butterfly, the epilogue.  The launch is a chain of memory round trips
+// per wave, so what matters is how many waves are resident (<= 64 registers: 8 per SIMD)
+// and how few dependent hops a position takes: no integer division anywhere (3-D grid,
+// precomputed records), halo entries written from 16-byte records (2 hops instead of 4).
+template <int CIN, int ITER, int BLOCK>
+__global__ __launch_bounds__(BLOCK, ITER <= 20 ? 8 : (ITER <= 40 ? 4 : 2)) void ee_step_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
-    const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
-    float *__restrict__ y, int cout, int constrain, int pad_out, int first_plane, int nplane, int split,
-    int psum) {
-  constexpr int RED = CIN * KK;
+    const uint32_t *__restrict__ tapoff, const float *__restrict__ bias, const float *__restrict__ slope,
+    const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum) {
   constexpr int kWaves = BLOCK / kWave;
-  // block -> (set, plane, image, part); everything a wave does per position is
-  // wave-uniform, so it is kept in scalar registers (readfirstlane)
-  int b = blockIdx.x;
-  const int part = b % split;
-  b /= split;
-  const int img = b % g.nimg;
-  b /= g.nimg;
-  const int pl = b % nplane;
-  const int set = b / nplane;
-  const int plane = first_plane + pl;
-  const int lo = g.plane_start[plane];
-  const int cnt = g.plane_start[plane + 1] - lo;
+  constexpr int SLOTS = ITER * kWave;
+  static_assert(SLOTS == slab_slots(CIN), "ITER must cover the padded reduction length");
+  const int part = blockIdx.x, split = gridDim.x;
+  const int plane = first_plane + blockIdx.y;
+  const int pn = blockIdx.z;  // replica-major image index: set * nimg + img
+  const int set = (pn >= g.nimg) + (pn >= 2 * g.nimg);
+  const int img = pn - set * g.nimg;
+  typedef const __attribute__((address_space(4))) int32_t const_i32_t;
+  const_i32_t *pstart = (const_i32_t *)g.plane_start;
+  const int lo = pstart[plane];
+  const int cnt = pstart[plane + 1] - lo;
+  if (part * kWaves >= cnt) return;  // uniform for the workgroup
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  if (!WLDS && part * kWaves + wave >= cnt) return;
   const int tc = psum - plane;
-  const int group_in = CIN / g.ngroup;
+  const int cout = GO * g.ngroup;
   const int h = g.h, w = g.w;
   const int win = w + 2 * PAD;
-  const int tile_elems = (h + 2 * PAD) * win * CIN;
-  const size_t out_img = (size_t)g.npart * (h + 2 * pad_out) * (w + 2 * pad_out) * cout;
-  const int slack = (constrain == 5) ? 0 : 1;
-  // causality: input group gi at (qh, pw) is usable iff gi + qh + pw < psum
-  // (constrain 5) or <= psum (constrain 6); qh + pw = row + tw - 4 + kh + kw, so
-  // the tap is usable iff ci < (tc + 4 - kh - kw + slack)*group_in.  A masked tap
-  // gets zero weights: fmaf(x, 0, acc) leaves acc unchanged (x is finite).
-  const int causal_base = (tc + slack) * group_in;
-  const float4 *slab = reinterpret_cast<const float4 *>(wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN));
-  constexpr int SLOTS = WLDS ? ITER * kWave : 1;
   __shared__ __attribute__((aligned(16))) float4 lw[SLOTS];
-  __shared__ unsigned lo4[SLOTS];
-  unsigned off[WLDS ? 1 : ITER];  // byte offsets: unsigned 32-bit, so the gathers are "scalar base + lane offset" loads
-  float w0[WLDS ? 1 : ITER], w1[WLDS ? 1 : ITER], w2[WLDS ? 1 : ITER];
-  if (WLDS) {
-    if (part * kWaves >= cnt) return;  // uniform for the workgroup
-    for (int kk = threadIdx.x; kk < SLOTS; kk += BLOCK) {
-      const int tap = kk / CIN, ci = kk - tap * CIN;
-      const int kh = tap / K, kw = tap - kh * K;
-      const bool ok = (kk < RED) && ((2 * HALF - kh - kw) * group_in - ci + causal_base > 0);
-      lw[kk] = ok ? slab[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
-      lo4[kk] = ok ? 4u * (unsigned)((kh * win + kw) * CIN + ci) : 0u;
-    }
-    __syncthreads();
-    if (part * kWaves + wave >= cnt) return;
-  } else {
-    TapWalk<CIN> tw(lane);
-#pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      const int kk = lane + it * kWave;
-      const bool ok = (kk < RED) && (tw.lim(group_in) + causal_base > 0);
-      off[it] = ok ? 4u * (unsigned)tw.off(win) : 0u;
-      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) wv = slab[kk];
-      w0[it] = wv.x;
-      w1[it] = wv.y;
-      w2[it] = wv.z;
-      tw.next();
-    }
+  {
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    const float4 *slab = reinterpret_cast<const float4 *>(wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN));
+    for (int i = wave; i < ITER; i += kWaves)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(slab + i * kWave + lane), (lds_ptr_t *)(lw + i * kWave), 16, 0, 0);
   }
+  unsigned off[ITER];  // byte offsets: unsigned 32-bit, so the gathers are "scalar base + lane offset" loads
+#pragma unroll
+  for (int it = 0; it < ITER; it++) off[it] = tapoff[it * kWave + lane];
   const int pout0 = tc * GO;
   const int bidx = set * cout + pout0;
   const float b0 = bias[bidx], b1 = bias[bidx + 1], b2 = bias[bidx + 2];
@@ -354,24 +315,32 @@ __global__ __launch_bounds__(BLOCK, WLDS ? 8 : waves_per_eu(ITER)) void ee_conv_
     s1 = slope[bidx + 1];
     s2 = slope[bidx + 2];
   }
-  const int pn = set * g.nimg + img;  // replica-major image index
-  const int xi = shared_input ? img : pn;
-  const float *ximg = x + (size_t)xi * g.npart * tile_elems;
+  const size_t in_img = (size_t)g.npart * (h + 2 * PAD) * win * CIN;
+  const size_t out_img = (size_t)g.npart * (h + 2 * pad_out) * (w + 2 * pad_out) * cout;
+  const float *ximg = x + (size_t)(shared_input ? img : pn) * in_img;
   float *yimg = y + (size_t)pn * out_img;
   const float *rimg = residual ? residual + (size_t)pn * out_img : nullptr;
+  __syncthreads();  // (waits for the DMA: vmcnt(0))
+  int e = part * kWaves + wave;
+  if (e >= cnt) return;
+  const int stride = split * kWaves;
+  // read-only table, wave-uniform index: through the constant address space these are
+  // scalar loads (s_load_dwordx4), not a vector load + readfirstlane
+  typedef const __attribute__((address_space(4))) EePos const_pos_t;
+  const_pos_t *plist = (const_pos_t *)(g.pos + lo);
+  EePos rec = plist[e];
 #pragma unroll 1
-  for (int e = part * kWaves + wave; e < cnt; e += split * kWaves) {
-    const Pos p = decode_pos(__builtin_amdgcn_readfirstlane(g.order[lo + e]), h, w);
-    // window origin (th-2+PAD, tw-2+PAD) = (th, tw) in padded coordinates
-    const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
-    const size_t oflat =
-        (((size_t)p.tg * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) + p.tw + pad_out) * cout + pout0;
+  for (;;) {
+    const int en = e + stride;
+    const EePos nxt = plist[en < cnt ? en : e];  // requested now, used by the next iteration
+    const float *xin = ximg + (size_t)rec.pix * CIN;     // window origin (row-2, col-2) in padded coordinates
+    const size_t oflat = (size_t)(pad_out ? rec.pix + 2 * win + 2 : rec.hw) * cout + pout0;
     float xv[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
       // (opaque to the optimiser: a zero-extension hoisted out of the loop would
       // turn every gather into a 64-bit VALU add + a 2-register address)
-      unsigned o = WLDS ? lo4[lane + it * kWave] : off[it];
+      unsigned o = off[it];
       asm volatile("" : "+v"(o));
       xv[it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
     }
@@ -384,16 +353,13 @@ __global__ __launch_bounds__(BLOCK, WLDS ? 8 : waves_per_eu(ITER)) void ee_conv_
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
-      if (WLDS) {
-        const float4 wv = lw[lane + it * kWave];
-        a0 = fmaf(xv[it], wv.x, a0);
-        a1 = fmaf(xv[it], wv.y, a1);
-        a2 = fmaf(xv[it], wv.z, a2);
-      } else {
-        a0 = fmaf(xv[it], w0[it], a0);
-        a1 = fmaf(xv[it], w1[it], a1);
-        a2 = fmaf(xv[it], w2[it], a2);
-      }
+      const float4 wv = lw[lane + it * kWave];
+      // (the padding float kept live: a 16-byte ds_read_b128 takes 4 LDS cycles, the
+      // 12-byte ds_read_b96 the compiler would otherwise pick takes 8)
+      asm volatile("" ::"v"(wv.w));
+      a0 = fmaf(xv[it], wv.x, a0);
+      a1 = fmaf(xv[it], wv.y, a1);
+      a2 = fmaf(xv[it], wv.z, a2);
     }
     // one packed butterfly; the row of 16 lanes a lane sits in decides which output it
     // finishes (rows 0 / 2 / 1,3 -> outputs 0 / 1 / 2), and the epilogue is spread the same way
@@ -408,27 +374,36 @@ __global__ __launch_bounds__(BLOCK, WLDS ? 8 : waves_per_eu(ITER)) void ee_conv_
     const bool writer = (lane & 15) == 0 && row != 3;  // one lane per output
     if (writer) yimg[oflat + o] = v;
     if (pad_out) {
-      const int valid = g.widths[p.tg];
-      if (p.tw < PAD && writer) yimg[oflat + (size_t)valid * cout + o] = v;  // circular wrap copy
-      if (p.th < PAD || p.th >= h - PAD) {
-        // this value feeds halo rows of the neighbouring tiles: the 16 lanes of a row
-        // share the entries that read it
-        const int grow = p.tg * h + p.th;
-        const int key = grow * w + p.tw;
-        const int rs = g.rev_start[key], n = g.rev_start[key + 1] - rs;
-        if (row != 3)
-          for (int k = lane & 15; k < n; k += 16)
-            halo_write<true>(g, yimg, cout, pout0 + o, g.rev_entry[rs + k], grow, p.tw, v);
+      if (rec.wrap && writer) yimg[oflat + (size_t)rec.wrap * cout + o] = v;  // circular wrap copy
+      const int nrev = rec.rev & 15;
+      if (nrev && row != 3) {
+        // this value feeds halo rows of the neighbouring tiles: the 16 lanes of a row share
+        // the entries interpolated from it
+        const EeHalo *hr = g.halo + (rec.rev >> 4);
+        const int ch = pout0 + o;
+        for (int k = lane & 15; k < nrev; k += 16) {
+          const EeHalo q = hr[k];
+          const float other = (q.info & (1 << 29)) ? v : (q.other >= 0 ? yimg[(size_t)q.other * cout + ch] : 0.f);
+          const float a = (q.info & (1 << 30)) ? other : v, b = (q.info & (1 << 30)) ? v : other;
+          const float hv = a * q.t + b * (1 - q.t);
+          float *dst = yimg + (size_t)q.dst * cout + ch;
+          *dst = hv;
+          const int wd = q.info & 0xffff;
+          if (wd) dst[(size_t)wd * cout] = hv;  // circular wrap of the first columns
+        }
       }
     }
+    if (en >= cnt) break;
+    rec = nxt;
+    e = en;
   }
 }
 
 // Encoder ("bulk") form of the same layer: every symbol is known, so a position
 // can be evaluated for ALL its channel groups at once.  A wave owns PP positions:
 // it gathers their 5 x 5 x CIN windows a single time, then walks the groups -- the
-// workgroup stages the group's weight rows in LDS, every lane reads its taps'
-// weights once (causally masked taps as zeros) and feeds the PP masked fmaf chains
+// workgroup stages the group's (pre-masked) slab in LDS, every lane reads its taps'
+// weights once (causally masked taps are zeros) and feeds the PP masked fmaf chains
 // + butterflies of its positions.  Per output the operations and their order are
 // exactly those of the step kernel above (psum = plane + group), so encoder and
 // decoder tables agree bit for bit.  Halos of the output are filled afterwards by
@@ -445,7 +420,6 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   const int chunk = blockIdx.x % nchunk;
   const int pn = blockIdx.x / nchunk;  // replica-major image index, 0 .. 3*nimg
   const int set = pn / g.nimg;
-  const int group_in = CIN / g.ngroup;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int h = g.h, w = g.w;
@@ -453,7 +427,6 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   const int tile_elems = (h + 2 * PAD) * win * CIN;
   const int xi = shared_input ? pn % g.nimg : pn;
   const float *ximg = x + (size_t)xi * g.npart * tile_elems;
-  const int slack = (constrain == 5) ? 0 : 1;
   const int idx0 = (chunk * (BLOCK / kWave) + wave) * PP;
   unsigned off[ITER];  // byte offsets of this lane's taps inside a window
   {
@@ -482,16 +455,14 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     obase[j] = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
                 p.tw + pad_out) * cout;
   }
-  stage_weights_masked<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x, group_in,
-                                   slack * group_in);
+  stage_weights<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x);
   __syncthreads();
   for (int tc = 0; tc < g.ngroup; tc++) {
     // the next group's slab goes to the other buffer while this one is used (its
     // last readers passed the barrier that ended the previous iteration)
     if (tc + 1 < g.ngroup)
-      stage_weights_masked<CIN, BLOCK>(wl2[(tc + 1) & 1],
-                                       wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN), threadIdx.x,
-                                       group_in, (tc + 1 + slack) * group_in);
+      stage_weights<CIN, BLOCK>(wl2[(tc + 1) & 1], wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN),
+                                threadIdx.x);
     const float *wl = wl2[tc & 1];
     float acc[PP][GO];
 #pragma unroll
@@ -548,24 +519,31 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   }
 }
 
-// decoder: one thread per (image, position) of the step that was just decoded
+// decoder: one thread per (image, position) of the step that was just decoded; grid.y = image
 __global__ void ee_scatter_kernel(EeGeom g, const float *__restrict__ packed, float *__restrict__ ctx, int lo,
                                   int len, int psum, float bias) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len * g.nimg) return;
-  const int l = i % len, n = i / len;
-  const int h = g.h, w = g.w, C = g.ngroup;
-  const Pos p = decode_pos(g.order[lo + l], h, w);
-  const int tc = psum - p.tw - p.row;
-  float *img = ctx + (size_t)n * g.npart * (h + 2 * PAD) * (w + 2 * PAD) * C;
-  const float v = packed[i] + bias;
-  const size_t dst = tile_elem(p.tg, p.th + PAD, p.tw + PAD, h, w, C) + tc;
-  img[dst] = v;
-  if (p.tw < PAD) img[dst + (size_t)g.widths[p.tg] * C] = v;
-  if (p.th < PAD || p.th >= h - PAD) {
-    const int key = p.row * w + p.tw;
-    const int r0 = g.rev_start[key], r1 = g.rev_start[key + 1];
-    for (int j = r0; j < r1; j++) halo_write<true>(g, img, C, tc, g.rev_entry[j], p.row, p.tw, v);
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= len) return;
+  const int n = blockIdx.y;
+  const int C = g.ngroup, win = g.w + 2 * PAD;
+  const EePos rec = g.pos[lo + l];
+  const int tc = psum - g.pos_plane[lo + l];
+  float *img = ctx + (size_t)n * g.npart * (g.h + 2 * PAD) * win * C;
+  const float v = packed[(size_t)n * len + l] + bias;
+  float *dst = img + (size_t)(rec.pix + 2 * win + 2) * C + tc;
+  *dst = v;
+  if (rec.wrap) dst[(size_t)rec.wrap * C] = v;
+  const int nrev = rec.rev & 15;
+  const EeHalo *hr = g.halo + (rec.rev >> 4);
+  for (int k = 0; k < nrev; k++) {
+    const EeHalo q = hr[k];
+    const float other = (q.info & (1 << 29)) ? v : (q.other >= 0 ? img[(size_t)q.other * C + tc] : 0.f);
+    const float a = (q.info & (1 << 30)) ? other : v, b = (q.info & (1 << 30)) ? v : other;
+    const float hv = a * q.t + b * (1 - q.t);
+    float *hd = img + (size_t)q.dst * C + tc;
+    *hd = hv;
+    const int wd = q.info & 0xffff;
+    if (wd) hd[(size_t)wd * C] = hv;
   }
 }
 
@@ -601,24 +579,28 @@ __global__ void ee_read_symbols_kernel(EeGeom g, const float *__restrict__ ctx, 
 __global__ void ee_tables_kernel(EeGeom g, const float *__restrict__ y, const float *__restrict__ symbols,
                                  int32_t *__restrict__ table, int32_t *__restrict__ labels, int lo, int len,
                                  int psum, int nstep, float bias, float total, float beta) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= len * g.nimg) return;
-  const int l = r % len, n = r / len;
-  const Pos p = decode_pos(g.order[lo + l], g.h, g.w);
-  const int tc = psum - p.tw - p.row;
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= len) return;
+  const int n = blockIdx.y;
+  const size_t r = (size_t)n * len + l;
+  const int hw = g.pos[lo + l].hw;
+  const int tc = psum - g.pos_plane[lo + l];
   const int cout = g.ngroup * 3;
+  const size_t plane_px = (size_t)g.npart * g.h * g.w;
   float par[3][3];
 #pragma unroll
   for (int rep = 0; rep < 3; rep++) {
-    const float *base =
-        y + ((((size_t)(rep * g.nimg + n) * g.npart + p.tg) * g.h + p.th) * g.w + p.tw) * cout + tc * 3;
+    const float *base = y + ((size_t)(rep * g.nimg + n) * plane_px + hw) * cout + tc * 3;
 #pragma unroll
     for (int k = 0; k < 3; k++) par[rep][k] = base[k];
   }
   gmm_prepare_row(par[0], par[1], 3, beta);
-  gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + (size_t)r * (nstep + 1));
-  if (symbols)
-    labels[r] = (int32_t)symbols[((((size_t)n * g.npart + p.tg) * g.ngroup + tc) * g.h + p.th) * g.w + p.tw];
+  gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
+  if (symbols) {
+    // NCHW symbol tensor: (image*npart + tile, group, row, col)
+    const int hwt = g.h * g.w, tg = hw / hwt, inner = hw - tg * hwt;
+    labels[r] = (int32_t)symbols[(((size_t)n * g.npart + tg) * g.ngroup + tc) * hwt + inner];
+  }
 }
 
 // all symbols at once, rows in stream order [step][img][position in the step's window]
@@ -664,10 +646,13 @@ int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, i
   return PCONV_OK;
 }
 
-int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, void *stream) {
+int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
+                   void *stream) {
+  PCONV_REQUIRE(cout == GO * ngroup && cin % ngroup == 0 && (constrain == 5 || constrain == 6),
+                "ee_pack_weight: bad layer shape");
   const int total = nset * (cout / GO) * slab_floats(cin);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), w, packed, cin,
-                     total);
+                     ngroup, constrain == 5 ? 0 : 1, total);
   PCONV_LAUNCH_CHECK("ee_pack_weight");
   return PCONV_OK;
 }
@@ -677,18 +662,20 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
             int first_plane, int nplane, int longest_plane, int psum, void *stream) {
   if (nplane <= 0 || longest_plane <= 0) return PCONV_OK;
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv: cout must be 3 per group");
+  PCONV_REQUIRE(cin == g->ngroup || cin == 3 * g->ngroup, "ee_conv: cin must be 1 or 3 per group");
+  (void)constrain;  // the causal mask is part of the packed slab
   constexpr int kWaves = kConvBlock / kWave;
-  // workgroups per (set, plane): enough to fill the chip, few enough that the
-  // weights a wave holds in registers serve several positions
-  int split = (longest_plane + kWaves * kPosPerWave - 1) / (kWaves * kPosPerWave);
+  // workgroups per (set, plane, image): enough to fill the chip, few enough that a
+  // staged slab serves several positions (PCONV_EE_PPW: positions per wave, tuning)
+  static const int ppw = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : kPosPerWave;
+  int split = (longest_plane + kWaves * ppw - 1) / (kWaves * ppw);
   if (split < 1) split = 1;
-  const long long grid = (long long)3 * nplane * g->nimg * split;
-  // weights in LDS while the slab fits a CU several times (measured at 42 input channels:
-  // decode of 4 lock-step frames 0.25 -> 0.20 s against the register form)
-#define EE_LAUNCH(CIN, ITER)                                                                                  \
-  hipLaunchKernelGGL((ee_conv_kernel<CIN, ITER, kConvBlock, (ITER <= 20)>), dim3((unsigned)grid),             \
-                     dim3(kConvBlock), 0, as_stream(stream), *g, x, shared_input, packed_w, bias, slope,      \
-                     residual, y, cout, constrain, pad_out, first_plane, nplane, split, psum)
+  const uint32_t *tap = cin == g->ngroup ? g->tap_in : g->tap_hid;
+  const dim3 grid((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));
+  PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images for one launch");
+#define EE_LAUNCH(CIN, ITER)                                                                                   \
+  hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, kConvBlock>), grid, dim3(kConvBlock), 0, as_stream(stream), *g, x, \
+                     shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum)
   if (cin == 14) {
     EE_LAUNCH(14, 6);
   } else if (cin == 42) {
@@ -760,9 +747,8 @@ int ee_halo_bulk(const EeGeom *g, float *buf, int C, int nrep, void *stream) {
 int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,
                void *stream) {
   if (len <= 0) return PCONV_OK;
-  const int n = len * g->nimg;
-  hipLaunchKernelGGL(ee_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), *g, packed, ctx, lo,
-                     len, psum, bias);
+  hipLaunchKernelGGL(ee_scatter_kernel, dim3((len + 255) / 256, g->nimg), dim3(256), 0, as_stream(stream), *g, packed,
+                     ctx, lo, len, psum, bias);
   PCONV_LAUNCH_CHECK("ee_scatter");
   return PCONV_OK;
 }
@@ -786,9 +772,8 @@ int ee_read_symbols(const EeGeom *g, const float *ctx, float *symbols, float bia
 int ee_tables(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels, int lo,
               int len, int psum, int nstep, float bias, float total, float beta, void *stream) {
   if (len <= 0) return PCONV_OK;
-  const int n = len * g->nimg;
-  hipLaunchKernelGGL(ee_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), *g, y_last, symbols,
-                     table, labels, lo, len, psum, nstep, bias, total, beta);
+  hipLaunchKernelGGL(ee_tables_kernel, dim3((len + 255) / 256, g->nimg), dim3(256), 0, as_stream(stream), *g, y_last,
+                     symbols, table, labels, lo, len, psum, nstep, bias, total, beta);
   PCONV_LAUNCH_CHECK("ee_tables");
   return PCONV_OK;
 }

@@ -254,9 +254,16 @@ def test_quant_train_mode_update_weight_and_histogram():
         x = torch.rand(16, 192, 2, 64, generator=g) * 1.2 - 0.1
         gv, gi = gop.forward(x.to(DEV), wg, cg, True)
         cv, ci = cop.forward(x, wc, cc, True)
-        same(gi, ci)
-        same(gv, cv)
-        same(gop.count_data_, cop.count_data_)
+        if it > 0 and it % check == 0:
+            # the merge ran inside this call, with torch's exp / log of either device: the
+            # level tables agree to an ulp, so do the values; an index may flip only for an
+            # input that sits on a decision boundary
+            assert (gv.cpu() - cv).abs().max().item() < 1e-5
+            assert (gi.cpu() != ci).float().mean().item() < 1e-4
+        else:
+            same(gi, ci)
+            same(gv, cv)
+            same(gop.count_data_, cop.count_data_)
         assert (wg.cpu() - wc).abs().max().item() < 1e-6, "level table diverged at call %d" % it
         assert (cg.cpu() - cc).abs().max().item() < 1e-6
         # the merge runs torch's exp / log on either device: keep the following kernel

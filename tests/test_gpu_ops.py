@@ -408,3 +408,44 @@ def test_tile_conv_depth_to_width_store(cfg):
             fused = P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16, d2w=True, ring=ring)
             assert tuple(fused.shape) == tuple(shuffled.shape)
             assert torch.equal(fused, shuffled)
+
+
+@pytest.mark.parametrize("cin,cout", [(192, 96), (96, 192), (192, 192), (192, 768)])
+def test_resident_1x1_equals_tiled_kernel(cin, cout, monkeypatch):
+    """the weight-resident 1x1 kernel (whole [K][BM] slab in LDS, B operands straight from
+    global memory, two row groups per workgroup) issues the same MFMA chain per output as the
+    tiled kernel: bit-identical results, ragged edges, every epilogue, strided views"""
+    tn, h, w = 16, 34, 1026
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(tn, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / np.sqrt(cin))).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    sl = torch.rand(cout, generator=g).to(DEV)
+    res = torch.randn(tn, cout, h, w, generator=g).to(DEV)
+    gate = torch.randn(tn, cout, h, w, generator=g).to(DEV)
+    limit = torch.tensor([w, 900, 513, 64, 65, 1, 1026, 700] * 2, dtype=torch.int32).to(DEV)
+    owner = type("Owner", (), {})()
+
+    def variants():
+        out = [P().tile_conv2d(owner, x, wt, b, 1, sl, limit, 16, residual=res, trim=True, ring=2).clone(),
+               P().tile_conv2d(owner, x, wt, b, 1, None, None, 0, sigmoid=True, gate=gate, residual=res).clone(),
+               P().tile_conv2d(owner, x, wt, None, 1, None, limit, 16).clone()]
+        if cout % 4 == 0:
+            out.append(P().tile_conv2d(owner, x, wt, b, 1, sl, limit, 16, d2w=True, ring=2).clone())
+        if cin == cout:
+            gam = (torch.rand(cin, cin, generator=torch.Generator().manual_seed(5)) * 0.01 + torch.eye(cin) * 0.1).to(DEV)
+            beta = (torch.rand(cin, generator=torch.Generator().manual_seed(6)) + 0.5).to(DEV)
+            for inverse in (False, True):
+                out.append(P().tile_gdn(owner, x, gam, beta, inverse, limit, 16, res, 2).clone())
+        return out
+
+    monkeypatch.setenv("PCONV_CONV1X1", "tiled")
+    tiled = variants()
+    monkeypatch.delenv("PCONV_CONV1X1")
+    resident = variants()
+    for i, (a, r) in enumerate(zip(tiled, resident)):
+        assert torch.isfinite(r).all()
+        assert torch.equal(a, r), "variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
+    # and against the oracle's fmaf chain on a slice of the batch
+    ref = O.conv2d_chain(x[:1].cpu(), wt.cpu(), None, 1, None)
+    assert torch.equal(resident[2][:1].cpu(), ref)   # tile 0 is live over its whole width
