@@ -903,15 +903,17 @@ conv_probe = None
 _VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack
 
 
-def conv_kernel_name(cout, k, stride, squared=False, cin=0):
+def conv_kernel_name(cout, k, stride, squared=False, cin=0, pixels=0):
     """the kernel instantiation pconv_conv2d / pconv_gdn pick for a layer (csrc/conv.hip), as
-    rocprofv3 prints it: the weight-resident conv1x1_resident_kernel<MT, WN, SQ> for 1x1
-    stride-1 layers whose slab fits LDS, else conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>"""
+    rocprofv3 prints it: the weight-resident conv1x1_rb_kernel<WM, SQ> for 1x1 stride-1 layers
+    whose slab fits LDS and that fill the chip, else conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>"""
     import os
     sq = "true" if squared else "false"
-    if k == 1 and stride == 1 and cin >= 32 and cin % 16 == 0 and cout > 32 and \
-            os.environ.get("PCONV_CONV1X1", "r")[0] != "t" and (cin + 15) // 16 * 16 * (192 if cout > 96 else 96) * 4 <= 150 * 1024:
-        return "conv1x1_resident_kernel<%d, 8, %s>" % (6 if cout > 96 else 3, sq)
+    mode = os.environ.get("PCONV_CONV1X1", "auto")[0]
+    if k == 1 and stride == 1 and cin >= 32 and cin % 16 == 0 and cout > 32 and mode != "t" and \
+            (cin + 15) // 16 * 16 * (192 if cout > 96 else 96) * 4 <= 150 * 1024 and \
+            (mode == "r" or (cout > 96 and pixels >= 256 * 1024)):
+        return "conv1x1_rb_kernel<%d, %s>" % (2 if cout > 96 else 1, sq)
     mt, nt, wm, wn = (3, 1, 2, 4) if cout > 96 else ((3, 1, 1, 8) if cout > 32 else (1, 1, 1, 4))
     return "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>" % (mt, nt, wm, wn, k, stride, 16 if k == 1 else 4, sq)
 
@@ -975,7 +977,7 @@ def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=N
          1 if inverse else 0, _ptr(col_limit), int(npart), _ptr(residual), ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
-        probe.records.append((conv_kernel_name(ch, 1, 1, True, cin=ch), "GDN %d w%d" % (ch, w),
+        probe.records.append((conv_kernel_name(ch, 1, 1, True, cin=ch, pixels=tn * h * w), "GDN %d w%d" % (ch, w),
                               2.0 * ch * ch * tn * h * w * _VALID_FRACTION, e0, e1))
     return out
 
@@ -1019,6 +1021,6 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
-        probe.records.append((conv_kernel_name(cout, k, stride, cin=cin), "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo),
+        probe.records.append((conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w), "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo),
                               flops, e0, e1))
     return out

@@ -384,32 +384,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
   conv_epilogue<MT, NT, WN>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half);
 }
 
-// ---- weight-resident 1x1 convolution ------------------------------------------------
-// The 1x1 layers (ResidualBlock conv1 / conv3, the attention gate, the shortcuts, and
-// the GDN contraction) have K = cin <= 192: per 16-channel chunk the tiled kernel above
-// does only 8 k-pairs of matrix work between two barriers, less than the LDS-DMA of the
-// next chunk needs to land (measured: matrix pipes 20-45 % busy, 0.14-0.27 of the
-// roof).  Here the WHOLE [K][BM] weight slab of the workgroup's cout block is staged in
-// LDS once (up to 144 KB: one workgroup per CU for BM = 192, two for BM = 96) and the
-// reduction loop has no barrier at all: a wave owns BM couts x 32 pixels, takes its A
-// operands from the slab and its B operands -- 32 consecutive pixels of channel 2kp
-// (lanes 0-31) and 2kp+1 (lanes 32-63), a coalesced 2 x 128-byte load -- straight from
-// global memory through an 8-deep register ring ("scalar base + lane offset" loads, the
-// base advances by two channels per k-pair).  A workgroup walks `passes` row groups of
-// ROWS = WN/2 rows x 64 columns with the same slab.  Same MFMA sequence per output as
-// the tiled kernel (k ascending from 0), same epilogue: the results are bit-identical.
+// ---- weight-resident, register-blocked 1x1 convolution ---------------------------------
+// The 1x1 layers (ResidualBlock conv1 / conv3, the attention gate, the up-sampling
+// shortcut, the GDN contraction) have K = cin <= 192.  In the tiled kernel above their
+// matrix loop is short (8 k-pairs per chunk, 6-12 chunks) next to what surrounds it: a
+// barrier and an LDS-DMA round per chunk and an epilogue of 48 four-byte loads / stores per
+// lane -- the matrix pipes are 20-45 % busy.  This kernel is built the other way round:
+//   * the WHOLE [K][BM] weight slab of the workgroup's cout block sits in LDS (<= 144 KB,
+//     staged once, one workgroup per CU) and the reduction loop has no barrier;
+//   * a wave owns 96 couts x 128 pixels: 3 x 4 accumulator tiles.  Lane l of either half
+//     holds 4 CONSECUTIVE pixels (4 l31 .. 4 l31 + 3) of one row: its B operands of a k-pair
+//     are ONE 16-byte load straight from global memory (channel 2kp for lanes 0-31, 2kp + 1
+//     for lanes 32-63; 2 x 512 contiguous bytes per wave instruction) through a register
+//     ring 6 deep -- 6 KB in flight per wave, 48 KB per CU -- and its results leave as
+//     16-byte stores (gate / residual / GDN input arrive as 16-byte loads): 12 instead of 48
+//     memory instructions per lane on the way out;
+//   * 12 MFMAs per k-pair against 3 LDS reads and 1 global load.
+// A workgroup = 8 waves = WM cout halves x (8 / WM) pixel groups, tile = ROWS rows x 256
+// columns, `passes` such tiles with the same slab.  Lanes past the right edge take the last
+// 4 columns instead (w - 4 .. w - 1): they recompute and rewrite their neighbours' values,
+// bit for bit, so there is no ragged path.  Per output the MFMA sequence is the tiled
+// kernel's (k ascending from 0) and so is the epilogue arithmetic: identical bits.
 typedef const __attribute__((address_space(1))) char global_bytes;  // (a global, not a flat, access)
-__device__ __forceinline__ float load_base_off(global_bytes *base, unsigned off) {
+__device__ __forceinline__ float4 load4_base_off(global_bytes *base, unsigned off) {
   asm volatile("" : "+v"(off));  // keeps the 32-bit lane offset out of a hoisted 64-bit add
-  return *reinterpret_cast<const __attribute__((address_space(1))) float *>(base + off);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = *reinterpret_cast<const __attribute__((address_space(1))) v4f *>(base + off);
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <int MT, int WN, bool SQ>
-__global__ __launch_bounds__(64 * WN, MT <= 3 ? 4 : 2) void conv1x1_resident_kernel(
+template <int WM, bool SQ>
+__global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int kpad, int h, int w,
     int cout, int cout_pad, int tiles_r, int tiles_c, int cblocks, int passes, ConvView vin, ConvView vout,
     ConvEpilogue ep) {
-  constexpr int kThreads = 64 * WN, BM = 32 * MT, ROWS = WN / 2, D = 8;
+  constexpr int kThreads = 512, MT = 3, NT = 4, BM = 96 * WM, WP = 8 / WM, ROWS = WP / 2, D = 5;
+  constexpr int kCols = 256;
   extern __shared__ float lds[];  // ws[kpad][BM]
   int b = blockIdx.x;
   const int cb = b % cblocks;
@@ -418,20 +428,19 @@ __global__ __launch_bounds__(64 * WN, MT <= 3 ? 4 : 2) void conv1x1_resident_ker
   b /= tiles_r;
   const int tcx = b % tiles_c;
   const int t = b / tiles_c;
-  const int c0 = tcx * kTileCols, cout0 = cb * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int cout0 = cb * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wq = wave / WM;  // cout half, pixel group
   const int l31 = lane & 31, half = lane >> 5;
   float *outp = out + (size_t)t * vout.ts;
   const float *inp = in + (size_t)t * vin.ts;
-  const int ho = h, wo = w;
-  if (ep.col_limit && c0 >= ep.col_limit[t % ep.npart]) {
-    for (int pass = 0; pass < passes; pass++) {
-      const int r0 = (trx * passes + pass) * ROWS;
-      if (r0 < ho) conv_zero_tile<BM, ROWS, kThreads>(outp, vout, ep.d2w, cout0, cout, r0, c0, ho, wo, tid);
-    }
-    return;
-  }
-  {
+  const int gc0 = tcx * kCols + (wq & 1) * 128;  // first column of the wave's pixel group
+  const int limit = ep.col_limit ? ep.col_limit[t % ep.npart] : w;
+  // the tiled kernel writes zeros from the first 64-column block that starts in the dead
+  // columns on; the same columns are zero here, whatever the epilogue
+  const int dead_at = ep.col_limit ? (limit + 63) / 64 * 64 : w;
+  const bool tile_dead = tcx * kCols >= dead_at;
+  if (!tile_dead) {
     typedef __attribute__((address_space(3))) void lds_ptr_t;
     typedef const __attribute__((address_space(1))) void glb_ptr_t;
     const int n4 = kpad * BM / 4;
@@ -440,76 +449,184 @@ __global__ __launch_bounds__(64 * WN, MT <= 3 ? 4 : 2) void conv1x1_resident_ker
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wp + (size_t)kk * cout_pad + cout0 + co),
                                        (lds_ptr_t *)(lds + (size_t)(e4 - lane) * 4), 16, 0, 0);
     }
+    __syncthreads();  // (waits for the DMA: vmcnt(0)); the only barrier of the kernel
   }
-  __syncthreads();  // (waits for the DMA: vmcnt(0))
+  if (gc0 >= w) return;  // the group lies past the right edge of the tensor
   const int KP = kpad / 2;
   const size_t kstep = (size_t)2 * vin.cs * sizeof(float);
-  const float *wsl = lds + half * BM + l31;
+  const float *wsl = lds + half * BM + wm * 96 + l31;
+  // this lane's 4 columns (the last 4 of the row for lanes past the edge)
+  const int col = gc0 + 4 * l31 < w - 4 ? gc0 + 4 * l31 : w - 4;
+  const bool group_dead = gc0 >= dead_at;
 #pragma unroll 1
   for (int pass = 0; pass < passes; pass++) {
-    const int r0 = (trx * passes + pass) * ROWS;
-    if (r0 >= ho) break;
-    int ir = r0 + (wn >> 1), ic = c0 + (wn & 1) * 32 + l31;
-    ir = ir < h ? ir : h - 1;
-    ic = ic < w ? ic : w - 1;
-    const unsigned loff = (unsigned)(((long long)half * vin.cs + (long long)ir * vin.rs + ic) * sizeof(float));
+    const int orow = (trx * passes + pass) * ROWS + (wq >> 1);
+    if (orow >= h) break;
+    // (cout0 made opaque per pass: otherwise the per-channel bias / slope loads of the
+    // epilogue are hoisted out of the pass loop and live across the matrix loop)
+    int cbase = __builtin_amdgcn_readfirstlane(cout0 + wm * 96);
+    asm volatile("" : "+s"(cbase));
+    if (group_dead) {
+      // whole group in the dead columns of this latitude band: zeros (128 columns of a cout
+      // row = 64 lanes x 2 columns)
+      const int c2 = gc0 + 2 * lane;
+#pragma unroll 1
+      for (int e = 0; e < 96; e++) {
+        const int co = cbase + e;
+        if (co >= cout) break;
+        for (int j = 0; j < 2; j++) {
+          if (c2 + j >= w) continue;
+          if (ep.d2w)
+            outp[(size_t)(co >> 2) * vout.cs + (size_t)(2 * orow + ((co >> 1) & 1)) * vout.rs + 2 * (c2 + j) + (co & 1)] = 0.f;
+          else
+            outp[(size_t)co * vout.cs + (size_t)orow * vout.rs + c2 + j] = 0.f;
+        }
+      }
+      continue;
+    }
+    const unsigned loff = (unsigned)(((long long)half * vin.cs + (long long)orow * vin.rs + col) * sizeof(float));
     // wave-uniform base in scalar registers: the loads are "SGPR base + lane offset"
     const unsigned long long in_u = reinterpret_cast<unsigned long long>(inp);
     global_bytes *bbase = reinterpret_cast<global_bytes *>(
         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(in_u >> 32)) << 32) |
         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)in_u));  // (int result: no sign extension)
-    f32x16 acc[MT][1];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[m][0][r] = 0.f;
-    float bq[D], a[2][MT];
+      for (int n = 0; n < NT; n++)
 #pragma unroll
-    for (int j = 0; j < D; j++) bq[j] = load_base_off(bbase + j * kstep, loff);
+        for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    float4 bq[D];
+    float a[2][MT];
+#pragma unroll
+    for (int j = 0; j < D; j++) bq[j] = load4_base_off(bbase + (size_t)(j < KP ? j : KP - 1) * kstep, loff);
 #pragma unroll
     for (int m = 0; m < MT; m++) a[0][m] = wsl[m * 32];
+    // one round = U k-pairs: a multiple of the ring depth (static ring slots) and of 2 (the
+    // two A fragment sets alternate)
+    constexpr int U = (D % 2) ? 2 * D : D;
 #pragma unroll 1
-    for (int kp0 = 0; kp0 < KP; kp0 += D) {
+    for (int kp0 = 0; kp0 < KP; kp0 += U) {
 #pragma unroll
-      for (int j = 0; j < D; j++) {
+      for (int j = 0; j < U; j++) {
         const int kp = kp0 + j;
-        float bv = bq[j];
-        // the ring always refills (past the end: the last k-pair again, never used) and the
-        // next A fragment is always read: no branches inside the matrix loop
-        const int kpre = kp + D < KP ? kp + D : KP - 1;
-        bq[j] = load_base_off(bbase + (size_t)kpre * kstep, loff);
-        const int knext = kp + 1 < KP ? kp + 1 : KP - 1;
+        if (kp < KP) {  // (the last round may be partial)
+          float4 bv = bq[j % D];
+          // the ring always refills (past the end: the last k-pair again, never used) and the
+          // next A fragment is always read: no data-dependent branch inside the matrix loop
+          const int kpre = kp + D < KP ? kp + D : KP - 1;
+          bq[j % D] = load4_base_off(bbase + (size_t)kpre * kstep, loff);
+          const int knext = kp + 1 < KP ? kp + 1 : KP - 1;
 #pragma unroll
-        for (int m = 0; m < MT; m++) a[(j + 1) & 1][m] = wsl[(size_t)knext * 2 * BM + m * 32];
-        if (SQ) bv = bv * bv;
-        __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < MT; m++) a[(j + 1) & 1][m] = wsl[(size_t)knext * 2 * BM + m * 32];
+          if (SQ) {
+            bv.x *= bv.x;
+            bv.y *= bv.y;
+            bv.z *= bv.z;
+            bv.w *= bv.w;
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < MT; m++)
-          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][m], bv, acc[m][0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < MT; m++) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][m], bv.x, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][m], bv.y, acc[m][1], 0, 0, 0);
+            acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][m], bv.z, acc[m][2], 0, 0, 0);
+            acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][m], bv.w, acc[m][3], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    // (cout0 made opaque per pass: otherwise the per-channel bias / slope loads of the
-    // epilogue are hoisted out of the pass loop and live -- 2 x BM of them -- across the
-    // matrix loop, which spills)
-    int cout0_pass = __builtin_amdgcn_readfirstlane(cout0);
-    asm volatile("" : "+s"(cout0_pass));
-    conv_epilogue<MT, 1, WN>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0_pass, cout, ho, wo, 0, wn, l31, half);
+    // ---- way out (ConvEpilogue), 4 consecutive pixels of one cout row per step ----
+    const int act = ep.act;
+    const int trim_at = ((ep.trim || act == 2 || act == 3) && ep.col_limit) ? limit : dead_at;
+    const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+    const float *gatep = ep.gate ? ep.gate + (size_t)t * ep.vgate.ts : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (ep.d2w && (r & 1)) continue;  // d2w stores the (r, r+1) cout pair together
+        const int co = cbase + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= cout) continue;
+        if (ep.d2w) {
+          // couts co (sx = 0) and co + 1 (sx = 1) of 4 pixels -> 8 consecutive outputs
+          const float b0 = ep.bias ? ep.bias[co] : 0.f, b1 = ep.bias ? ep.bias[co + 1] : 0.f;
+          const float s0 = (act == 1) ? ep.slope[co] : 0.f, s1 = (act == 1) ? ep.slope[co + 1] : 0.f;
+          float v0[4] = {acc[m][0][r] + b0, acc[m][1][r] + b0, acc[m][2][r] + b0, acc[m][3][r] + b0};
+          float v1[4] = {acc[m][0][r + 1] + b1, acc[m][1][r + 1] + b1, acc[m][2][r + 1] + b1, acc[m][3][r + 1] + b1};
+          if (act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (v0[j] < 0) v0[j] = v0[j] * s0;
+              if (v1[j] < 0) v1[j] = v1[j] * s1;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (col + j >= trim_at) v0[j] = v1[j] = 0.f;
+          float *q = outp + (size_t)(co >> 2) * vout.cs + (size_t)(2 * orow + ((co >> 1) & 1)) * vout.rs + 2 * col;
+          *reinterpret_cast<float4 *>(q) = make_float4(v0[0], v1[0], v0[1], v1[1]);
+          *reinterpret_cast<float4 *>(q + 4) = make_float4(v0[2], v1[2], v0[3], v1[3]);
+          continue;
+        }
+        const float bco = ep.bias ? ep.bias[co] : 0.f;
+        const float sl = (act == 1) ? ep.slope[co] : 0.f;
+        float v[4] = {acc[m][0][r] + bco, acc[m][1][r] + bco, acc[m][2][r] + bco, acc[m][3][r] + bco};
+        if (act == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (v[j] < 0) v[j] = v[j] * sl;
+        } else if (act == 2 || act == 3) {
+          // 1x1, stride 1: input and output share their geometry
+          const float4 xv = *reinterpret_cast<const float4 *>(inp + (size_t)co * vin.cs + (size_t)orow * vin.rs + col);
+          const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float nrm = sqrtf(v[j]);
+            v[j] = act == 2 ? xs[j] / nrm : xs[j] * nrm;
+          }
+        } else if (act == 4) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = 1.f / (1.f + expf(-v[j]));
+        }
+        if (gatep) {
+          const float4 gv = *reinterpret_cast<const float4 *>(gatep + (size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + col);
+          v[0] = gv.x * v[0];
+          v[1] = gv.y * v[1];
+          v[2] = gv.z * v[2];
+          v[3] = gv.w * v[3];
+        }
+        if (resp) {
+          const float4 rv = *reinterpret_cast<const float4 *>(resp + (size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + col);
+          v[0] = rv.x + v[0];
+          v[1] = rv.y + v[1];
+          v[2] = rv.z + v[2];
+          v[3] = rv.w + v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (col + j >= trim_at) v[j] = 0.f;
+        *reinterpret_cast<float4 *>(outp + (size_t)co * vout.cs + (size_t)orow * vout.rs + col) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
   }
 }
 
-template <int MT, int WN, bool SQ>
+template <int WM, bool SQ>
 int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout,
                    int cout_pad, const ConvView &vin, const ConvView &vout, const ConvEpilogue &ep,
                    hipStream_t stream) {
-  constexpr int BM = 32 * MT, ROWS = WN / 2;
+  constexpr int BM = 96 * WM, ROWS = (8 / WM) / 2;
   const int kpad = (cin + 15) / 16 * 16;
-  const int tiles_c = (w + kTileCols - 1) / kTileCols;
+  const int tiles_c = (w + 255) / 256;
   const int cblocks = (cout + BM - 1) / BM;
-  // two row groups per workgroup (the slab is staged once for both) while that still
-  // leaves >= 4 workgroups per CU-slot
+  // several row groups per workgroup (the slab is staged once for all of them) while that
+  // still leaves >= 4 workgroups per CU
   const long long single = (long long)tn * ((h + ROWS - 1) / ROWS) * tiles_c * cblocks;
-  const int passes = single >= 2048 ? 2 : 1;
+  const int passes = single >= 4096 ? 4 : (single >= 2048 ? 2 : 1);
   const int tiles_r = (h + ROWS * passes - 1) / (ROWS * passes);
   const long long grid = (long long)tn * tiles_r * tiles_c * cblocks;
   if (grid <= 0 || grid > 0x7fffffffLL) {
@@ -517,7 +634,7 @@ int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin
     return PCONV_EINVAL;
   }
   const size_t smem = (size_t)kpad * BM * sizeof(float);
-  auto kern = conv1x1_resident_kernel<MT, WN, SQ>;
+  auto kern = conv1x1_rb_kernel<WM, SQ>;
   if (smem > 64 * 1024) {
     static std::atomic<unsigned long long> raised{0};
     int device = 0;
@@ -533,19 +650,27 @@ int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin
       raised.fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WN), smem, stream, in, wp, out, kpad, h, w, cout,
-                     cout_pad, tiles_r, tiles_c, cblocks, passes, vin, vout, ep);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, in, wp, out, kpad, h, w, cout, cout_pad,
+                     tiles_r, tiles_c, cblocks, passes, vin, vout, ep);
   return PCONV_OK;
 }
 
-// the weight-resident form takes 1x1 stride-1 layers whose slab fits LDS
+// the weight-resident form takes 1x1 stride-1 layers whose slab fits LDS and that are big
+// enough to fill the chip with 512-pixel workgroup tiles; 16-byte accesses need the views'
+// strides and bases to be multiples of 2 floats... they only need 4-byte alignment on
+// gfx950 (unaligned dwordx4 access is enabled), so any view qualifies
 // (PCONV_CONV1X1=tiled forces the tiled kernel: A/B measurements and the parity tests)
-inline bool use_resident_1x1(int cin, int cout) {
+inline bool use_resident_1x1(int cin, int cout, int tn, int h, int w) {
   const char *env = getenv("PCONV_CONV1X1");
   if (env && env[0] == 't') return false;
   const int kpad = (cin + 15) / 16 * 16;
   const int bm = cout > 96 ? 192 : 96;
-  return cin >= 32 && cin % 16 == 0 && cout > 32 && (size_t)kpad * bm * sizeof(float) <= 150 * 1024;
+  if (!(cin >= 32 && cin % 16 == 0 && cout > 32 && (size_t)kpad * bm * sizeof(float) <= 150 * 1024)) return false;
+  if (w < 4) return false;
+  if (env && env[0] == 'r') return true;  // forced (tests)
+  // measured (MI355X, 4096x2048 frame): 96->192, 192->192 and the GDN gain 10-25 % at the
+  // quarter / half scales; the 96-cout layers (one cout block, 1024-pixel tiles) lose 10 %
+  return cout > 96 && (long long)tn * h * w >= 256LL * 1024;
 }
 
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded
@@ -685,11 +810,11 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
     BY_TILE(3, 1, 4)
   } else if (k == 3 && stride == 2) {
     BY_TILE(3, 2, 4)
-  } else if (k == 1 && stride == 1 && use_resident_1x1(cin, cout)) {
+  } else if (k == 1 && stride == 1 && use_resident_1x1(cin, cout, tn, h, w)) {
     if (cout > 96)
-      rc = launch_conv1x1<6, 8, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+      rc = launch_conv1x1<2, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
     else
-      rc = launch_conv1x1<3, 8, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+      rc = launch_conv1x1<1, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
   } else if (k == 1 && stride == 1) {
     BY_TILE(1, 1, 16)
   } else {
@@ -723,10 +848,10 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
   PCONV_REQUIRE(view_ok(vin, ch, h, w) && view_ok(vout, ch, h, w) && (!residual || view_ok(ep.vres, ch, h, w)),
                 "gdn: strides overlap");
   int rc;
-  if (use_resident_1x1(ch, ch) && ch > 96)
-    rc = launch_conv1x1<6, 8, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
-  else if (use_resident_1x1(ch, ch))
-    rc = launch_conv1x1<3, 8, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  if (use_resident_1x1(ch, ch, tn, h, w) && ch > 96)
+    rc = launch_conv1x1<2, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  else if (use_resident_1x1(ch, ch, tn, h, w))
+    rc = launch_conv1x1<1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
   else if (ch > 96)
     rc = launch_conv<3, 1, 2, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)

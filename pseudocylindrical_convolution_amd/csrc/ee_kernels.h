@@ -87,14 +87,19 @@ int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, i
 // its interior (bulk mode, after a layer has been evaluated everywhere)
 int ee_halo_bulk(const EeGeom *g, float *buf, int C, int nrep, void *stream);
 
-// decoder: symbols of one step (packed [img][l]) + bias into ctx (nimg images)
+// decoder: symbols of one step (packed [img][l]) + bias into ctx (nimg images).  flags != null
+// (pinned host memory): the kernel first waits until flags[0] >= wait_for -- the host
+// publishes the decoded symbols there -- so it can be queued before they exist; relay: a
+// zeroed device int through which the one polling block tells the others.
 int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,
-               void *stream);
+               int32_t *flags, int32_t *relay, int wait_for, void *stream);
 // encoder: all symbols (NCHW float indices) + bias into a zeroed ctx
 int ee_fill_ctx(const EeGeom *g, const float *symbols, float *ctx, float bias, void *stream);
 // decoder epilogue: ctx -> NCHW symbols (index = value - bias), zero in dead columns
 int ee_read_symbols(const EeGeom *g, const float *ctx, float *symbols, float bias, void *stream);
 // integer CDF rows of one step from the last layer's output (unpadded, 3*ngroup
-// channels); optional labels from the NCHW symbol tensor
+// channels); optional labels from the NCHW symbol tensor.  flags != null: once all rows are
+// written the kernel stores flags[1] = publish (system scope); counter: a zeroed device int.
 int ee_tables(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
-              int lo, int len, int psum, int nstep, float bias, float total, float beta, void *stream);
+              int lo, int len, int psum, int nstep, float bias, float total, float beta, int32_t *counter,
+              int32_t *flags, int publish, void *stream);

@@ -161,6 +161,8 @@ struct Group {
   int32_t *tables_d = nullptr, *labels_d = nullptr;
   int32_t *tables_h = nullptr, *labels_h = nullptr;  // pinned
   float *packed_h = nullptr;                         // pinned; decoder: symbols of the previous step [img][len]
+  int32_t *flags_h = nullptr;                        // pinned, coherent: decoder chain flags (entropy_engine.hip)
+  int32_t *counter_d = nullptr;                      // device: finished blocks of the running table kernel
   int32_t *step_row_d = nullptr;
   std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
   std::vector<int32_t> sym;
@@ -229,6 +231,9 @@ struct pconv_entropy_engine {
     HIP_TRY(hipHostMalloc(&g.tables_h, all_rows * (nlevels + 1) * 4));
     HIP_TRY(hipHostMalloc(&g.labels_h, all_rows * 4));
     HIP_TRY(hipHostMalloc(&g.packed_h, (size_t)n * max_len * 4));
+    HIP_TRY(hipHostMalloc(&g.flags_h, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(hipMalloc(&g.counter_d, 64));
+    HIP_TRY(hipMemset(g.counter_d, 0, 64));
     return PCONV_OK;
   }
 
@@ -389,6 +394,8 @@ struct pconv_entropy_engine {
       if (g.tables_h) (void)hipHostFree(g.tables_h);
       if (g.labels_h) (void)hipHostFree(g.labels_h);
       if (g.packed_h) (void)hipHostFree(g.packed_h);
+      if (g.flags_h) (void)hipHostFree(g.flags_h);
+      freed(g.counter_d);
       if (g.done) (void)hipEventDestroy(g.done);
       if (g.stream) (void)hipStreamDestroy(g.stream);
     }
@@ -412,6 +419,7 @@ struct pconv_entropy_engine {
   }
 
   int clear(Group &g) {
+    HIP_TRY(hipMemsetAsync(g.counter_d, 0, 64, g.stream));  // table-kernel block counter, scatter relay word
     HIP_TRY(hipMemsetAsync(g.ctx, 0, ctx_elems(g.nimg) * 4, g.stream));
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(g.act[l], 0, act_elems(l, g.nimg) * 4, g.stream));
     return PCONV_OK;
@@ -462,7 +470,8 @@ struct pconv_entropy_engine {
         const Window cur = window(s);
         PC_TRY(network_step(g, s, cur));
         PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], sym, g.tables_d + (size_t)g.step_row[s] * cols,
-                         g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, g.stream));
+                         g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, nullptr, nullptr, 0,
+                         g.stream));
       }
     } else {
       PC_TRY(network_bulk(g));
@@ -474,30 +483,28 @@ struct pconv_entropy_engine {
     return PCONV_OK;
   }
 
-  // decoder, GPU phase of step s for one group (everything is queued, nothing waits)
-  int decode_enqueue(Group &g, int s, const Window &prev, const Window &cur) {
-    const int cols = nlevels + 1;
+  // decoder, GPU phase of step s for one group (everything is queued, nothing waits).
+  // chained: the scatter kernel waits in memory for the host's symbols and the table kernel
+  // publishes its rows there, so the step can be queued long before its inputs exist.
+  int decode_enqueue(Group &g, int s, const Window &prev, const Window &cur, bool chained) {
     // Zero-copy both ways: the scatter kernel reads the decoded symbols from the pinned host
     // buffer and the table kernel writes its rows into pinned host memory (both are
     // device-visible), which removes two copy launches and their gaps from every step.
-    if (s > 0) PC_TRY(ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, s - 1, -bias, g.stream));
+    int32_t *flags = chained ? g.flags_h : nullptr;
+    if (s > 0)
+      PC_TRY(ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, s - 1, -bias, flags, g.counter_d + 8, s, g.stream));
     if (cur.len > 0) {
       PC_TRY(network_step(g, s, cur));
       PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_h, nullptr, cur.lo, cur.len, s, nlevels, bias,
-                       total, beta, g.stream));
+                       total, beta, g.counter_d, flags, s + 1, g.stream));
     }
-    (void)cols;
     return PCONV_OK;
   }
 
-  // decoder, CPU phase of step s for one group: wait for its tables, decode, send the symbols back
-  int decode_symbols(Group &g, int s, const Window &cur, double *t_wait, double *t_coder) {
-    if (cur.len <= 0) return PCONV_OK;
+  // arithmetic decoding of one step's rows (already in tables_h) for the frames of a group
+  int decode_rows(Group &g, int s, const Window &cur) {
     const int cols = nlevels + 1;
     const size_t nrow = (size_t)cur.len * g.nimg;
-    const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    const auto t1 = std::chrono::steady_clock::now();
     g.sym.resize(nrow);
     std::atomic<int> status{0};
     const std::function<void(int)> job = [&](int i) {
@@ -513,10 +520,51 @@ struct pconv_entropy_engine {
       pconv_set_error("ee_decode: arithmetic decoder desynchronised at step %d", s);
       return PCONV_EINVAL;
     }
+    return PCONV_OK;
+  }
+
+  // decoder, CPU phase of step s for one group, host-driven chain: wait for the stream,
+  // decode, leave the symbols for the next step's scatter
+  int decode_symbols(Group &g, int s, const Window &cur, double *t_wait, double *t_coder) {
+    if (cur.len <= 0) return PCONV_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    PC_TRY(decode_rows(g, s, cur));
     const auto t2 = std::chrono::steady_clock::now();
     *t_wait += std::chrono::duration<double>(t1 - t0).count();
     *t_coder += std::chrono::duration<double>(t2 - t1).count();
     return PCONV_OK;
+  }
+
+  // the same for the queued-ahead chain: the table kernel announces its rows in flags[1]
+  // and the next scatter kernel waits for flags[0]; `failed`: the queueing thread gave up
+  int decode_symbols_chained(Group &g, int s, const Window &cur, const std::atomic<int> &failed, double *t_wait,
+                             double *t_coder) {
+    volatile int32_t *flags = g.flags_h;
+    int rc = PCONV_OK;
+    if (cur.len > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      long long spins = 0;
+      while (__atomic_load_n(&flags[1], __ATOMIC_ACQUIRE) < s + 1) {
+        cpu_relax();
+        if ((++spins & 0xfffff) == 0) {
+          if (failed.load(std::memory_order_acquire) || __atomic_load_n(&flags[2], __ATOMIC_ACQUIRE) ||
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+            pconv_set_error("ee_decode: the GPU chain stopped before step %d", s);
+            return PCONV_ELAUNCH;
+          }
+        }
+      }
+      const auto t1 = std::chrono::steady_clock::now();
+      rc = decode_rows(g, s, cur);
+      const auto t2 = std::chrono::steady_clock::now();
+      *t_wait += std::chrono::duration<double>(t1 - t0).count();
+      *t_coder += std::chrono::duration<double>(t2 - t1).count();
+    }
+    // symbols of step s are in packed_h (x86 stores stay in order; the GPU reads coherent memory)
+    if (rc >= 0) __atomic_store_n(&flags[0], s + 1, __ATOMIC_RELEASE);
+    return rc;
   }
 };
 
@@ -653,46 +701,116 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
   const bool timing = getenv("PCONV_ENGINE_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   PC_TRY(e->fork(caller));
-  // One host thread per group.  A group's step is a chain -- 14 back-to-back launches,
-  // table copy, host wait, arithmetic decoding, symbol copy, next step -- of which the
-  // GPU part is latency-bound and the host part serial, so the chains of the groups
-  // simply run side by side: every group has its own stream, pinned buffers, coders and
-  // now its own driver, and nothing orders one group's step against another's.
+  // A group's step is a chain -- scatter, 12 layers, tables on the GPU, then arithmetic
+  // decoding on the CPU -- of which the GPU part is latency-bound and the host part serial,
+  // so the chains of the groups run side by side: every group has its own stream, pinned
+  // buffers and coders, and nothing orders one group's step against another's.
+  //   queued chain (default): per group one thread queues ALL steps ahead -- each step's
+  //     scatter kernel waits in memory for the symbols, its table kernel announces the rows
+  //     there -- and a second thread only polls, decodes and publishes: no launch and no
+  //     stream synchronisation on the critical path of a step;
+  //   PCONV_ENGINE_CHAIN=host: the host launches a step after it has decoded the previous
+  //     one (kept as the checker of the queued chain: tests/test_gpu_engine.py).
+  const char *chain_env = getenv("PCONV_ENGINE_CHAIN");
+  const bool chained = !(chain_env && chain_env[0] == 'h');
   const int ng = (int)e->groups.size();
   std::vector<int> rcs(ng, PCONV_OK);
   std::vector<std::string> errors(ng);
   std::vector<double> waits(ng, 0.0), coders(ng, 0.0);
+  std::vector<std::atomic<int>> failed(ng);
+  for (auto &f : failed) f.store(0);
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
+  auto fail = [&](int k, int rc) {  // first error of a group wins; the message lives in the failing thread
+    if (rcs[k] >= 0) {
+      rcs[k] = rc;
+      errors[k] = pconv_last_error();
+    }
+  };
+  // queues every launch of group k's decode (queued chain)
+  auto queue_all = [&](int k) {
+    if (hipSetDevice(device) != hipSuccess) {
+      pconv_set_error("ee_decode: hipSetDevice failed in a group thread");
+      failed[k].store(1, std::memory_order_release);
+      return PCONV_ELAUNCH;
+    }
+    Group &g = e->groups[k];
+    int rc = e->clear(g);
+    Window prev = {0, 0, 0, 0};
+    for (int s = 0; s < e->nsteps && rc >= 0; s++) {
+      const Window cur = e->window(s);
+      rc = e->decode_enqueue(g, s, prev, cur, true);
+      prev = cur;
+    }
+    // the symbols of the last step have not been scattered by a following step yet
+    if (rc >= 0)
+      rc = ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, g.flags_h,
+                      g.counter_d + 8, e->nsteps, g.stream);
+    if (rc >= 0)
+      rc = ee_read_symbols(&g.geom, g.ctx, symbols_out + (size_t)g.first * e->image_symbols(), e->bias, g.stream);
+    if (rc < 0) failed[k].store(1, std::memory_order_release);
+    return rc;
+  };
   auto drive = [&](int k) {
     // a new thread starts on device 0: bind it to the engine's GPU (ranks of a
     // multi-GPU job each drive their own device)
     if (hipSetDevice(device) != hipSuccess) {
-      errors[k] = "ee_decode: hipSetDevice failed in a group driver";
-      rcs[k] = PCONV_ELAUNCH;
+      pconv_set_error("ee_decode: hipSetDevice failed in a group driver");
+      fail(k, PCONV_ELAUNCH);
       return;
     }
     Group &g = e->groups[k];
     StepPool pool(g.nimg);
     g.pool = &pool;
-    int rc = e->clear(g);
-    Window prev = {0, 0, 0, 0};
-    for (int s = 0; s < e->nsteps && rc >= 0; s++) {
-      const Window cur = e->window(s);
-      rc = e->decode_enqueue(g, s, prev, cur);
-      if (rc >= 0) rc = e->decode_symbols(g, s, cur, &waits[k], &coders[k]);
-      prev = cur;
-    }
-    // the symbols of the last step have not been scattered by a following step yet
-    if (rc >= 0) rc = ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, g.stream);
-    if (rc >= 0)
-      rc = ee_read_symbols(&g.geom, g.ctx, symbols_out + (size_t)g.first * e->image_symbols(), e->bias, g.stream);
-    if (rc < 0) {
-      errors[k] = pconv_last_error();  // the message lives in this thread
-      (void)hipStreamSynchronize(g.stream);
+    int rc = PCONV_OK;
+    if (chained) {
+      g.flags_h[0] = g.flags_h[1] = g.flags_h[2] = 0;
+      int qrc = PCONV_OK;
+      std::string qerr;
+      std::thread queuer([&] {
+        qrc = queue_all(k);
+        if (qrc < 0) qerr = pconv_last_error();
+      });
+      for (int s = 0; s < e->nsteps && rc >= 0; s++)
+        rc = e->decode_symbols_chained(g, s, e->window(s), failed[k], &waits[k], &coders[k]);
+      if (rc < 0) {
+        fail(k, rc);
+        // let the queued kernels run out: they only wait for this flag
+        __atomic_store_n(&g.flags_h[0], 0x7fffffff, __ATOMIC_RELEASE);
+      }
+      queuer.join();
+      if (qrc < 0 && rcs[k] >= 0) {
+        rcs[k] = qrc;
+        errors[k] = qerr;
+      }
+      if (hipStreamSynchronize(g.stream) != hipSuccess && rcs[k] >= 0) {
+        rcs[k] = PCONV_ELAUNCH;
+        errors[k] = "ee_decode: the decode stream failed";
+      }
+      if (g.flags_h[2] && rcs[k] >= 0) {
+        rcs[k] = PCONV_ELAUNCH;
+        errors[k] = "ee_decode: a scatter kernel timed out waiting for symbols";
+      }
+    } else {
+      rc = e->clear(g);
+      Window prev = {0, 0, 0, 0};
+      for (int s = 0; s < e->nsteps && rc >= 0; s++) {
+        const Window cur = e->window(s);
+        rc = e->decode_enqueue(g, s, prev, cur, false);
+        if (rc >= 0) rc = e->decode_symbols(g, s, cur, &waits[k], &coders[k]);
+        prev = cur;
+      }
+      if (rc >= 0)
+        rc = ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, e->nsteps - 1, -e->bias, nullptr, nullptr, 0,
+                        g.stream);
+      if (rc >= 0)
+        rc = ee_read_symbols(&g.geom, g.ctx, symbols_out + (size_t)g.first * e->image_symbols(), e->bias, g.stream);
+      if (rc < 0) {
+        fail(k, rc);
+        (void)hipStreamSynchronize(g.stream);
+      }
     }
     g.pool = nullptr;
-    rcs[k] = rc;
   };
   {
     std::vector<std::thread> drivers;

@@ -272,7 +272,7 @@ __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict
 // and how few dependent hops a position takes: no integer division anywhere (3-D grid,
 // precomputed records), halo entries written from 16-byte records (2 hops instead of 4).
 template <int CIN, int ITER, int BLOCK>
-__global__ __launch_bounds__(BLOCK, ITER <= 20 ? 8 : (ITER <= 40 ? 4 : 2)) void ee_step_kernel(
+__global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER <= 20 ? 8 : (ITER <= 40 ? 4 : 2))) void ee_step_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const uint32_t *__restrict__ tapoff, const float *__restrict__ bias, const float *__restrict__ slope,
     const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum) {
@@ -326,13 +326,20 @@ __global__ __launch_bounds__(BLOCK, ITER <= 20 ? 8 : (ITER <= 40 ? 4 : 2)) void 
   const int stride = split * kWaves;
   // read-only table, wave-uniform index: through the constant address space these are
   // scalar loads (s_load_dwordx4), not a vector load + readfirstlane
-  typedef const __attribute__((address_space(4))) EePos const_pos_t;
-  const_pos_t *plist = (const_pos_t *)(g.pos + lo);
-  EePos rec = plist[e];
+  const_i32_t *plist = (const_i32_t *)(g.pos + lo);
+  auto load_pos = [&](int i) {
+    EePos p;
+    p.pix = plist[4 * i];
+    p.hw = plist[4 * i + 1];
+    p.wrap = plist[4 * i + 2];
+    p.rev = plist[4 * i + 3];
+    return p;
+  };
+  EePos rec = load_pos(e);
 #pragma unroll 1
   for (;;) {
     const int en = e + stride;
-    const EePos nxt = plist[en < cnt ? en : e];  // requested now, used by the next iteration
+    const EePos nxt = load_pos(en < cnt ? en : e);  // requested now, used by the next iteration
     const float *xin = ximg + (size_t)rec.pix * CIN;     // window origin (row-2, col-2) in padded coordinates
     const size_t oflat = (size_t)(pad_out ? rec.pix + 2 * win + 2 : rec.hw) * cout + pout0;
     float xv[ITER];
@@ -519,9 +526,45 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   }
 }
 
-// decoder: one thread per (image, position) of the step that was just decoded; grid.y = image
+// Decoder chain flags: three int32 in pinned (coherent) host memory per group, so that the
+// host never launches on the critical path of a step -- the whole chain of a decode is
+// queued ahead and its two ends talk through memory (engine.cpp):
+//   flags[0]  host -> GPU   s+1 once the symbols of step s are in packed_h
+//   flags[1]  GPU -> host   s+1 once the CDF rows of step s are in tables_h
+//   flags[2]  GPU -> host   a scatter kernel gave up waiting (bounded spin)
+// Only block (0, 0) polls the host flag (every poll is a PCIe round trip; dozens of pollers
+// slow the fabric down for everybody); it passes the value on through a device word the
+// other blocks of the launch poll in L2.
+__device__ __forceinline__ void chain_wait(volatile int32_t *flags, int32_t *relay, int wait_for) {
+  if (threadIdx.x == 0) {
+    const bool leader = blockIdx.x == 0 && blockIdx.y == 0;
+    int32_t *word = leader ? const_cast<int32_t *>(flags) : relay;
+    const long long t0 = wall_clock64();  // 100 MHz
+    for (;;) {
+      const int seen = leader ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                              : __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen >= wait_for) break;
+      if (leader)
+        __builtin_amdgcn_s_sleep(16);
+      else
+        __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 600000000LL) {  // 6 s: the host side is gone; every wave still exits
+        __hip_atomic_store(const_cast<int32_t *>(flags) + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+    if (leader) __hip_atomic_store(relay, wait_for, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  __syncthreads();
+}
+
+// decoder: one thread per (image, position) of the step that was just decoded; grid.y = image.
+// flags != null: first wait until the host has published the symbols (flags[0] >= wait_for).
 __global__ void ee_scatter_kernel(EeGeom g, const float *__restrict__ packed, float *__restrict__ ctx, int lo,
-                                  int len, int psum, float bias) {
+                                  int len, int psum, float bias, volatile int32_t *flags, int32_t *relay,
+                                  int wait_for) {
+  if (flags) chain_wait(flags, relay, wait_for);
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= len) return;
   const int n = blockIdx.y;
@@ -576,30 +619,116 @@ __global__ void ee_read_symbols_kernel(EeGeom g, const float *__restrict__ ctx, 
   }
 }
 
+// flags != null: the block that finishes last publishes flags[1] = publish (system scope)
+// after every block's rows are out; `counter` (device, zero) counts the finished blocks.
 __global__ void ee_tables_kernel(EeGeom g, const float *__restrict__ y, const float *__restrict__ symbols,
                                  int32_t *__restrict__ table, int32_t *__restrict__ labels, int lo, int len,
-                                 int psum, int nstep, float bias, float total, float beta) {
+                                 int psum, int nstep, float bias, float total, float beta, int32_t *counter,
+                                 volatile int32_t *flags, int publish) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= len) return;
-  const int n = blockIdx.y;
-  const size_t r = (size_t)n * len + l;
-  const int hw = g.pos[lo + l].hw;
-  const int tc = psum - g.pos_plane[lo + l];
-  const int cout = g.ngroup * 3;
-  const size_t plane_px = (size_t)g.npart * g.h * g.w;
-  float par[3][3];
+  if (l < len) {
+    const int n = blockIdx.y;
+    const size_t r = (size_t)n * len + l;
+    const int hw = g.pos[lo + l].hw;
+    const int tc = psum - g.pos_plane[lo + l];
+    const int cout = g.ngroup * 3;
+    const size_t plane_px = (size_t)g.npart * g.h * g.w;
+    float par[3][3];
 #pragma unroll
-  for (int rep = 0; rep < 3; rep++) {
-    const float *base = y + ((size_t)(rep * g.nimg + n) * plane_px + hw) * cout + tc * 3;
+    for (int rep = 0; rep < 3; rep++) {
+      const float *base = y + ((size_t)(rep * g.nimg + n) * plane_px + hw) * cout + tc * 3;
 #pragma unroll
-    for (int k = 0; k < 3; k++) par[rep][k] = base[k];
+      for (int k = 0; k < 3; k++) par[rep][k] = base[k];
+    }
+    gmm_prepare_row(par[0], par[1], 3, beta);
+    gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
+    if (symbols) {
+      // NCHW symbol tensor: (image*npart + tile, group, row, col)
+      const int hwt = g.h * g.w, tg = hw / hwt, inner = hw - tg * hwt;
+      labels[r] = (int32_t)symbols[(((size_t)n * g.npart + tg) * g.ngroup + tc) * hwt + inner];
+    }
   }
-  gmm_prepare_row(par[0], par[1], 3, beta);
-  gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
-  if (symbols) {
-    // NCHW symbol tensor: (image*npart + tile, group, row, col)
-    const int hwt = g.h * g.w, tg = hw / hwt, inner = hw - tg * hwt;
-    labels[r] = (int32_t)symbols[(((size_t)n * g.npart + tg) * g.ngroup + tc) * hwt + inner];
+  if (flags) {
+    __syncthreads();  // every wave of the block has drained its stores (vmcnt(0) before the barrier)
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      const int nblocks = gridDim.x * gridDim.y;
+      if (atomicAdd(counter, 1) == nblocks - 1) {
+        *counter = 0;  // ready for the next step of this stream
+        __threadfence_system();
+        __hip_atomic_store(const_cast<int32_t *>(flags) + 1, publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// The same rows with EIGHT lanes per row (nstep == 8): lane q of an octet evaluates CDF entry
+// q + 1 (the 3-gaussian sum of the one-thread form, same operations in the same order), the
+// octet exchanges its 8 raw entries and every lane runs the short monotonicity repair on
+// them, then stores its own entry.  The one-thread form spends ~21 erf evaluations per thread
+// in a launch of a few hundred waves: pure latency, 3x longer than a layer of the network.
+__global__ void ee_tables8_kernel(EeGeom g, const float *__restrict__ y, int32_t *__restrict__ table, int lo,
+                                  int len, int psum, float bias, float total, float beta, int32_t *counter,
+                                  volatile int32_t *flags, int publish) {
+  constexpr int NS = 8;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = tid >> 3, q = tid & 7;
+  const bool live = l < len;
+  const int n = blockIdx.y;
+  float cur = 0.f;
+  if (live) {
+    const int hw = g.pos[lo + l].hw;
+    const int tc = psum - g.pos_plane[lo + l];
+    const int cout = g.ngroup * 3;
+    const size_t plane_px = (size_t)g.npart * g.h * g.w;
+    float par[3][3];
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {
+      const float *base = y + ((size_t)(rep * g.nimg + n) * plane_px + hw) * cout + tc * 3;
+#pragma unroll
+      for (int k = 0; k < 3; k++) par[rep][k] = base[k];
+    }
+    gmm_prepare_row(par[0], par[1], 3, beta);
+    cur = gmm_cdf_entry(par[0], par[1], par[2], 3, NS, q + 1, bias, total);
+  }
+  // raw entries 1..8 of the row, from the 8 lanes of the octet (all lanes of the wave take part)
+  float raw[NS];
+  const int lane = threadIdx.x & 63, base_lane = lane & ~7;
+#pragma unroll
+  for (int i = 0; i < NS; i++) raw[i] = __shfl(cur, base_lane + i, 64);
+  if (live) {
+    // check kernel (entropy_gmm_table_cuda.cu:83-105): compares the raw entry with the already
+    // shifted previous one, keeps every bin >= 1 count, takes the counts back from the widest bin
+    float prev = 0.f, shift = 0.f, widest = 0.f, mine = 0.f;
+    int widest_at = 0;
+#pragma unroll
+    for (int pt = 1; pt <= NS; pt++) {
+      float c = raw[pt - 1];
+      if (c <= prev) shift += 1;
+      c += shift;
+      if (c - prev > widest) {
+        widest = c - prev;
+        widest_at = pt - 1;
+      }
+      if (pt == q + 1) mine = c;
+      prev = c;
+    }
+    if (shift > 0 && q >= widest_at) mine = (float)(int32_t)mine - shift;
+    int32_t *row = table + ((size_t)n * len + l) * (NS + 1);
+    row[q + 1] = (int32_t)mine;
+    if (q == 0) row[0] = 0;
+  }
+  if (flags) {
+    __syncthreads();  // every wave of the block has drained its stores (vmcnt(0) before the barrier)
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      const int nblocks = gridDim.x * gridDim.y;
+      if (atomicAdd(counter, 1) == nblocks - 1) {
+        *counter = 0;  // ready for the next step of this stream
+        __threadfence_system();
+        __hip_atomic_store(const_cast<int32_t *>(flags) + 1, publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -664,18 +793,28 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv: cout must be 3 per group");
   PCONV_REQUIRE(cin == g->ngroup || cin == 3 * g->ngroup, "ee_conv: cin must be 1 or 3 per group");
   (void)constrain;  // the causal mask is part of the packed slab
-  constexpr int kWaves = kConvBlock / kWave;
-  // workgroups per (set, plane, image): enough to fill the chip, few enough that a
-  // staged slab serves several positions (PCONV_EE_PPW: positions per wave, tuning)
+  // workgroups per (set, plane, image): enough to fill the chip, few enough that a staged
+  // slab serves several positions.  PCONV_EE_BLOCK (threads per workgroup: 256 / 512 / 1024)
+  // and PCONV_EE_PPW (positions a wave walks) are tuning knobs.
+  static const int block = getenv("PCONV_EE_BLOCK") ? atoi(getenv("PCONV_EE_BLOCK")) : kConvBlock;
   static const int ppw = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : kPosPerWave;
-  int split = (longest_plane + kWaves * ppw - 1) / (kWaves * ppw);
+  const int waves = block / kWave;
+  int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;
   const uint32_t *tap = cin == g->ngroup ? g->tap_in : g->tap_hid;
   const dim3 grid((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));
   PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images for one launch");
-#define EE_LAUNCH(CIN, ITER)                                                                                   \
-  hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, kConvBlock>), grid, dim3(kConvBlock), 0, as_stream(stream), *g, x, \
+#define EE_LAUNCH_B(CIN, ITER, BLK)                                                                          \
+  hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, BLK>), grid, dim3(BLK), 0, as_stream(stream), *g, x,         \
                      shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum)
+#define EE_LAUNCH(CIN, ITER)              \
+  if (block == 1024) {                    \
+    EE_LAUNCH_B(CIN, ITER, 1024);         \
+  } else if (block == 512) {              \
+    EE_LAUNCH_B(CIN, ITER, 512);          \
+  } else {                                \
+    EE_LAUNCH_B(CIN, ITER, 256);          \
+  }
   if (cin == 14) {
     EE_LAUNCH(14, 6);
   } else if (cin == 42) {
@@ -693,6 +832,7 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
     return PCONV_EINVAL;
   }
 #undef EE_LAUNCH
+#undef EE_LAUNCH_B
   PCONV_LAUNCH_CHECK("ee_conv");
   return PCONV_OK;
 }
@@ -745,10 +885,10 @@ int ee_halo_bulk(const EeGeom *g, float *buf, int C, int nrep, void *stream) {
 }
 
 int ee_scatter(const EeGeom *g, const float *packed, float *ctx, int lo, int len, int psum, float bias,
-               void *stream) {
+               int32_t *flags, int32_t *relay, int wait_for, void *stream) {
   if (len <= 0) return PCONV_OK;
   hipLaunchKernelGGL(ee_scatter_kernel, dim3((len + 255) / 256, g->nimg), dim3(256), 0, as_stream(stream), *g, packed,
-                     ctx, lo, len, psum, bias);
+                     ctx, lo, len, psum, bias, (volatile int32_t *)flags, relay, wait_for);
   PCONV_LAUNCH_CHECK("ee_scatter");
   return PCONV_OK;
 }
@@ -770,10 +910,18 @@ int ee_read_symbols(const EeGeom *g, const float *ctx, float *symbols, float bia
 }
 
 int ee_tables(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels, int lo,
-              int len, int psum, int nstep, float bias, float total, float beta, void *stream) {
+              int len, int psum, int nstep, float bias, float total, float beta, int32_t *counter, int32_t *flags,
+              int publish, void *stream) {
   if (len <= 0) return PCONV_OK;
+  if (nstep == 8 && !symbols) {  // the decoder's form: 8 lanes per row
+    hipLaunchKernelGGL(ee_tables8_kernel, dim3((len * 8 + 255) / 256, g->nimg), dim3(256), 0, as_stream(stream), *g,
+                       y_last, table, lo, len, psum, bias, total, beta, counter, (volatile int32_t *)flags, publish);
+    PCONV_LAUNCH_CHECK("ee_tables");
+    return PCONV_OK;
+  }
   hipLaunchKernelGGL(ee_tables_kernel, dim3((len + 255) / 256, g->nimg), dim3(256), 0, as_stream(stream), *g, y_last,
-                     symbols, table, labels, lo, len, psum, nstep, bias, total, beta);
+                     symbols, table, labels, lo, len, psum, nstep, bias, total, beta, counter,
+                     (volatile int32_t *)flags, publish);
   PCONV_LAUNCH_CHECK("ee_tables");
   return PCONV_OK;
 }

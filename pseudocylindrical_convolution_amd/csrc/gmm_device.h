@@ -22,6 +22,20 @@ __device__ __forceinline__ void gmm_prepare_row(float *wt, float *dl, int ng, fl
   }
 }
 
+// raw entry pt (1..nstep) of the integer CDF, before the monotonicity repair: exactly the
+// value `cur` of gmm_cdf_row below at that pt (batch arithmetic, :148)
+__device__ __forceinline__ float gmm_cdf_entry(const float *wt, const float *dl, const float *mu, int ng, int nstep,
+                                               int pt, float bias, float total) {
+  if (pt == nstep) return static_cast<int>(total);
+  const float s2 = 1. / sqrt(2.0);
+  float v = pt - 1 - bias + 0.5, ps = 0;
+  for (int k = 0; k < ng; k++) {
+    const float e = pconv_erff(s2 * (v - mu[k]) / dl[k]);
+    ps = ps + wt[k] * (0.5 + 0.5 * e);  // double inside, as :148
+  }
+  return static_cast<int>(total * ps + 0.5);
+}
+
 // row[0..nstep]: integer CDF with the reference's monotonicity repair applied on
 // the fly (every bin at least one count, taken back from the widest bin)
 template <typename Out>

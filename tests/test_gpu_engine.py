@@ -122,3 +122,25 @@ def test_engine_full_size_properties(hip_backend):
     rec = eng.decode(both, H, W)
     assert tuple(rec.shape) == (2, 3, H, W) and torch.isfinite(rec).all()
     assert torch.equal(rec, torch.cat([dec.reconstruct(sym[:16]), dec.reconstruct(sym[16:])], 0))
+
+
+def test_queued_chain_equals_host_driven_chain(hip_backend, monkeypatch):
+    """the decoder's queued-ahead chain (scatter kernels wait in pinned memory for the host's
+    symbols, table kernels announce their rows there) returns exactly what the host-driven
+    loop returns, for one frame and for a lock-step batch in two groups"""
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = _codec()
+    eng = CodecEngine(56, 0, enc, dec)
+    x = _frames(3, 256, 512, seed=13)
+    streams = eng.encode(x)
+    sym = eng.symbols(x)
+    for n in (1, 3):
+        e = eng._engine("dec", sym.shape[2], sym.shape[3], n)
+        queued = e.decode(streams[:n])
+        monkeypatch.setenv("PCONV_ENGINE_CHAIN", "host")
+        host = e.decode(streams[:n])
+        monkeypatch.delenv("PCONV_ENGINE_CHAIN")
+        assert torch.equal(queued, host)
+        assert torch.equal(queued, sym[:16 * n])
+        again = e.decode(streams[:n])   # flags and counters are back in their initial state
+        assert torch.equal(again, queued)

@@ -410,12 +410,15 @@ def test_tile_conv_depth_to_width_store(cfg):
             assert torch.equal(fused, shuffled)
 
 
-@pytest.mark.parametrize("cin,cout", [(192, 96), (96, 192), (192, 192), (192, 768)])
-def test_resident_1x1_equals_tiled_kernel(cin, cout, monkeypatch):
-    """the weight-resident 1x1 kernel (whole [K][BM] slab in LDS, B operands straight from
-    global memory, two row groups per workgroup) issues the same MFMA chain per output as the
-    tiled kernel: bit-identical results, ragged edges, every epilogue, strided views"""
-    tn, h, w = 16, 34, 1026
+@pytest.mark.parametrize("cin,cout,shape", [(192, 96, (16, 34, 1026)), (96, 192, (16, 34, 1026)),
+                                            (192, 192, (16, 34, 1026)), (192, 768, (16, 18, 514)),
+                                            (192, 192, (16, 3, 70)), (96, 96, (2, 5, 7))])
+def test_resident_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
+    """the weight-resident, register-blocked 1x1 kernel (whole [K][BM] slab in LDS, 16-byte B
+    loads straight from global memory, 16-byte stores, several row groups per workgroup)
+    issues the same MFMA chain per output as the tiled kernel: bit-identical results, ragged
+    edges (lanes past the edge recompute the last 4 columns), every epilogue, strided views"""
+    tn, h, w = shape
     g = torch.Generator().manual_seed(47)
     x = torch.randn(tn, cin, h, w, generator=g).to(DEV)
     wt = (torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / np.sqrt(cin))).to(DEV)
@@ -423,7 +426,7 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, monkeypatch):
     sl = torch.rand(cout, generator=g).to(DEV)
     res = torch.randn(tn, cout, h, w, generator=g).to(DEV)
     gate = torch.randn(tn, cout, h, w, generator=g).to(DEV)
-    limit = torch.tensor([w, 900, 513, 64, 65, 1, 1026, 700] * 2, dtype=torch.int32).to(DEV)
+    limit = torch.tensor([w, (w * 7) // 8, w // 2 + 1, 64, 65, 1, w, 130] * 2, dtype=torch.int32).clamp(max=w).to(DEV)
     owner = type("Owner", (), {})()
 
     def variants():
@@ -432,6 +435,7 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, monkeypatch):
                P().tile_conv2d(owner, x, wt, None, 1, None, limit, 16).clone()]
         if cout % 4 == 0:
             out.append(P().tile_conv2d(owner, x, wt, b, 1, sl, limit, 16, d2w=True, ring=2).clone())
+            out.append(P().tile_conv2d(owner, x, wt, b, 1, None, None, 0, d2w=True).clone())
         if cin == cout:
             gam = (torch.rand(cin, cin, generator=torch.Generator().manual_seed(5)) * 0.01 + torch.eye(cin) * 0.1).to(DEV)
             beta = (torch.rand(cin, generator=torch.Generator().manual_seed(6)) + 0.5).to(DEV)
@@ -441,8 +445,9 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, monkeypatch):
 
     monkeypatch.setenv("PCONV_CONV1X1", "tiled")
     tiled = variants()
-    monkeypatch.delenv("PCONV_CONV1X1")
+    monkeypatch.setenv("PCONV_CONV1X1", "resident")
     resident = variants()
+    monkeypatch.delenv("PCONV_CONV1X1")
     for i, (a, r) in enumerate(zip(tiled, resident)):
         assert torch.isfinite(r).all()
         assert torch.equal(a, r), "variant %d: max abs diff %g" % (i, (a - r).abs().max().item())

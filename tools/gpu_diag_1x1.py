@@ -5,6 +5,7 @@ import numpy as np, torch
 from pseudocylindrical_convolution_amd import PCONV
 from oracle import pconv_cpu as O
 cfgs = [(2, 192, 4, 70, 96), (1, 96, 3, 64, 192)]
+os.environ.setdefault("PCONV_CONV1X1", "resident")
 if len(sys.argv) > 1:
     cfgs = [tuple(int(v) for v in sys.argv[1:6])]
 for tn, cin, h, w, cout in cfgs:
