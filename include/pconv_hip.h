@@ -170,6 +170,39 @@ int pconv_project(const float *in, const float *tf, float *out, int n, int c, in
 int pconv_context_reshape(const float *in, float *out, int n, int c, int h, int w, int ngroup,
                           void *stream);
 
+/* ---- backward (transposed) forms of the linear geometry ops: training path, SURVEY 8f-4 ---- */
+
+/* ContextReshapeOp.backward (context_reshape_cuda.cu:63-95): (n*g*h*w, cpg) -> (n, g*cpg, h, w) */
+int pconv_context_reshape_backward(const float *top, float *bottom, int n, int c, int h, int w,
+                                   int ngroup, void *stream);
+
+/* SphereSliceOp.backward (sphere_slice_cuda.cu:191-244): grad of the tile stack
+ * (n*npart, c, height/npart + 2*pad, width + 2*pad) -> grad of the image (n, c, height, width).
+ * Same tap tables as the forward call. */
+int pconv_sphere_slice_backward(const float *gout, float *gin, const int32_t *widths,
+                                const int32_t *tap_col, const float *tap_coef, int n, int c,
+                                int height, int width, int npart, int pad, void *stream);
+
+/* SphereUsliceOp.backward (sphere_uslice_cuda.cu:128-200): grad of the image (n, c, h*npart, width)
+ * -> grad of the tile stack (n*npart, c, h + 2*pad, width + 2*pad), zero outside the valid interior */
+int pconv_sphere_uslice_backward(const float *gout, float *gin, const int32_t *widths,
+                                 const int32_t *tap_col, const float *tap_coef, int n, int c, int h,
+                                 int width, int npart, int pad, void *stream);
+
+/* Reverse of pconv_host_pad_table: CSR over interior elements (tile*height + row)*width + col ->
+ * halo entries that read the element, (destination tile << 24 | padded row*width + column, weight).
+ * rev_start: npart*height*width + 1 ints; rev_dst / rev_wgt: up to 4*npart*pad*width records.
+ * Returns the number of records.  Replaces pseudo_context_backward_kernel
+ * (pseudo_context_cuda.cu:106-138), whose atomics-built lists have no defined order. */
+int pconv_host_pad_reverse(const int32_t *widths, int npart, int height, int width, int pad,
+                           int32_t *rev_start, int32_t *rev_dst, float *rev_wgt);
+
+/* PseudoPadOp.backward (pseudo_pad.cu:127-235): grad (tn, c, h+2p, w+2p) -> (tn, c, h, w); gout is
+ * not modified (the reference folds the wrap columns into its argument in place) */
+int pconv_pseudo_pad_backward(const float *gout, float *gin, const int32_t *widths,
+                              const int32_t *rev_start, const int32_t *rev_dst, const float *rev_wgt,
+                              int tn, int c, int h, int w, int pad, int npart, void *stream);
+
 /* MaskConstrainOp.forward, in place on a conv weight (nout, cin, k, k)
  * (mask_constrain_cuda.cu:19-88); constrain in {1,2,5,6} */
 int pconv_mask_constrain(float *weight, int nout, int cin, int k, int ngroup, int constrain,

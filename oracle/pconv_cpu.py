@@ -200,6 +200,15 @@ class DtowOp(_Base):
         lib().orc_dtow(_p(x), _p(out), I(n), I(c), I(h), I(w), I(s), I(1 if self.d2w_ else 0))
         return [out]
 
+    def backward(self, grad):
+        # dtow_cuda.cu:105-167: bottom_diff[index] = top_diff[where the forward sent index]
+        n, c, h, w = grad.shape
+        s = self.stride_
+        shape = (n, c * s * s, h // s, w // s) if self.d2w_ else (n, c // (s * s), h * s, w * s)
+        out = self._top(1, shape)
+        lib().orc_dtow(_p(grad.contiguous()), _p(out), I(n), I(c), I(h), I(w), I(s), I(0 if self.d2w_ else 1))
+        return [out]
+
 
 class ContextReshapeOp(_Base):
 
@@ -210,8 +219,15 @@ class ContextReshapeOp(_Base):
     def forward(self, x):
         n, c, h, w = x.shape
         cpg = c // self.ngroup_
+        self.shape_ = (n, c, h, w)
         out = self._top(0, (n * h * w * self.ngroup_, cpg))
         lib().orc_context_reshape(_p(x), _p(out), I(n), I(c), I(h), I(w), I(cpg))
+        return [out]
+
+    def backward(self, grad):
+        n, c, h, w = self.shape_
+        out = self._top(1, (n, c, h, w))
+        lib().orc_context_reshape_backward(_p(out), _p(grad.contiguous()), I(n), I(c), I(h), I(w), I(c // self.ngroup_))
         return [out]
 
 
@@ -228,6 +244,11 @@ class EntropyGmmOp(_Base):
         lib().orc_gmm_loss(_p(weight), _p(delta), _p(mean), _p(label), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]),
                            _p(loss), I(m), I(ng))
         return [loss]
+
+    def backward(self, grad):
+        # entropy_gmm_cuda.cu:95-127: the stored per-row derivatives times the incoming gradient
+        g = grad.reshape(-1, 1)
+        return [self.top[1] * g, self.top[2] * g, self.top[3] * g, self.top[4] * g]
 
 
 class MaskConstrainOp(_Base):
@@ -265,7 +286,16 @@ class SphereSliceOp(_Base):
         out = self._top(0, (n * self.npart_, c, h_out + 2 * p, w + 2 * p), zero=True)
         lib().orc_slice_forward(_p(x), _p(out), _p(param), _p(tidx), I(n * self.npart_), I(c), I(h_out), I(w),
                                 I(h), I(self.npart_), I(p))
+        self.shape_ = (n, c, h, w)
         return [out]
+
+    def backward(self, grad):
+        n, c, h, w = self.shape_
+        tidx, param, h_out = self.tabs[(h, w)]
+        gin = self._top(1, (n, c, h, w))
+        lib().orc_slice_backward(_p(gin), _p(grad.contiguous()), _p(param), _p(tidx), I(n * self.npart_), I(c), I(h_out),
+                                 I(w), I(h), I(self.npart_), I(self.pad_))
+        return [gin]
 
 
 class SphereUsliceOp(_Base):
@@ -292,6 +322,15 @@ class SphereUsliceOp(_Base):
         lib().orc_uslice_forward(_p(x), _p(out), _p(param), _p(hidx), I(n_out), I(c), I(h), I(w), I(self.npart_), I(p))
         return [out]
 
+    def backward(self, grad):
+        n_out, c, hh, w = grad.shape
+        h, p = hh // self.npart_, self.pad_
+        hidx, param = self.tabs[(h, w)]
+        gin = self._top(1, (n_out * self.npart_, c, h + 2 * p, w + 2 * p))
+        lib().orc_uslice_backward(_p(gin), _p(grad.contiguous()), _p(param), _p(hidx), I(n_out), I(c), I(h), I(w),
+                                  I(self.npart_), I(p))
+        return [gin]
+
 
 class PseudoPadOp(_Base):
 
@@ -310,6 +349,16 @@ class PseudoPadOp(_Base):
         lib().orc_pseudo_pad(_p(x), _p(out), _p(hidx), _p(h2), _p(dst), _p(src), _p(pcol), _p(pt), I(num), I(c),
                              I(h), I(w), I(self.npart_), I(p))
         return [out]
+
+    def backward(self, grad):
+        num, c, hp, wp = grad.shape
+        p = self.pad_
+        h, w = hp - 2 * p, wp - 2 * p
+        hidx, h2, dst, src, pcol, pt = self.ctx_.produce_param(c, h, w, p)
+        gin = self._top(1, (num, c, h, w))
+        lib().orc_pseudo_pad_backward(_p(grad.contiguous()), _p(gin), _p(hidx), _p(h2), _p(dst), _p(src), _p(pcol),
+                                      _p(pt), I(num), I(c), I(h), I(w), I(self.npart_), I(p))
+        return [gin]
 
 
 class PseudoFillOp(_Base):

@@ -1089,3 +1089,140 @@ void orc_conv2d_chain(const float *in, const float *w, const float *bias, const 
     out[o] = acc;
   }
 }
+
+/* ========================================================================================
+ * Backward of the linear geometry ops (training path).  The reference sums
+ * through float atomics / atomics-built inverse lists, i.e. in no defined order; these
+ * restatements run the same scatter sequentially in index order.
+ * ====================================================================================== */
+
+/* ---- sphere_slice_cuda.cu:191-244 ---------------------------------------------------- */
+void orc_slice_backward(float *input, const float *output, const float *param, const int *hindex,
+                        int num_out, int channel, int height, int width, int height_in, int npart,
+                        int pad) {
+  const int stride_h = height + 2 * pad, stride_w = width + 2 * pad;
+  const i64 nthreads = (i64)num_out * channel * height * width;
+  const i64 nin = (i64)(num_out / npart) * channel * height_in * width;
+  for (i64 i = 0; i < nin; i++) input[i] = 0; /* caffe_gpu_set(..., 0, bottom_diff) */
+  for (i64 index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int th = (index / width) % height;
+    int tc = (index / width / height) % channel;
+    int tn = index / width / height / channel;
+    i64 oidx = (((i64)tn * channel + tc) * stride_h + th + pad) * stride_w + tw + pad;
+    int pn = tn / npart;
+    int pt = tn % npart;
+    int ph = pt > 0 ? th + hindex[pt - 1] : th;
+    if (tw >= hindex[pt + npart]) continue;
+    int base = (pt * width + tw) * 5;
+    int pw = (int)param[base];
+    i64 pidx = (((i64)pn * channel + tc) * height_in + ph) * width;
+    if (pw > 0 && pw < width - 2) {
+      input[pidx + pw - 1] += output[oidx] * param[base + 1];
+      input[pidx + pw] += output[oidx] * param[base + 2];
+      input[pidx + pw + 1] += output[oidx] * param[base + 3];
+      input[pidx + pw + 2] += output[oidx] * param[base + 4];
+    } else {
+      input[pidx + (pw - 1 + width) % width] += output[oidx] * param[base + 1];
+      input[pidx + pw] += output[oidx] * param[base + 2];
+      input[pidx + (pw + 1) % width] += output[oidx] * param[base + 3];
+      input[pidx + (pw + 2) % width] += output[oidx] * param[base + 4];
+    }
+  }
+}
+
+/* ---- sphere_uslice_cuda.cu:128-200: the inverse lists of :128-155 hold, for every valid
+ * source column, the output columns whose 4 taps touch it, with the tap weight; the gather
+ * of :157-179 sums output * weight over a list.  Same sums as the scatter below. ---------- */
+void orc_uslice_backward(float *input, const float *output, const float *param, const int *hindex,
+                         int n_out, int channel, int height, int width, int npart, int pad) {
+  const int height_out = height * npart;
+  const int stride_h = height + 2 * pad, stride_w = width + 2 * pad;
+  const i64 nin = (i64)n_out * npart * channel * stride_h * stride_w;
+  for (i64 i = 0; i < nin; i++) input[i] = 0;
+  const i64 nthreads = (i64)n_out * channel * height_out * width;
+  for (i64 index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int th = (index / width) % height_out;
+    int tc = (index / width / height_out) % channel;
+    int tn = index / width / height_out / channel;
+    int ph = th % height;
+    int pb = th / height;
+    int pn = tn * npart + pb;
+    int base = (pb * width + tw) * 5;
+    int pw = (int)param[base];
+    i64 pidx = (((i64)pn * channel + tc) * stride_h + ph + pad) * stride_w + pad;
+    int wl = hindex[pb];
+    if (pw > 0 && pw < wl - 2) {
+      for (int j = -1; j < 3; j++) input[pidx + pw + j] += output[index] * param[base + j + 2];
+    } else {
+      for (int j = -1; j < 3; j++) input[pidx + (pw + j + wl) % wl] += output[index] * param[base + j + 2];
+    }
+  }
+}
+
+/* ---- pseudo_pad.cu:127-235 with the inverse lists of pseudo_context_cuda.cu:106-138 ------
+ * top_diff is copied first: the reference folds the wrap columns into its argument in place. */
+void orc_pseudo_pad_backward(const float *top_diff, float *bottom_diff, const int *hindex, const int *hindex2,
+                             const i64 *dstoff, const i64 *srcoff, const int *pcol, const float *pt, int num,
+                             int channel, int height, int width, int npart, int pad) {
+  const int h_out = height + 2 * pad, w_out = width + 2 * pad;
+  const i64 nout = (i64)num * channel * h_out * w_out;
+  float *out = (float *)malloc(sizeof(float) * (size_t)nout);
+  for (i64 i = 0; i < nout; i++) out[i] = top_diff[i];
+  /* pseudo_pad_circle_backward_lfour_kernel (:175-193; the other variant does the same adds) */
+  const i64 nrows = (i64)num * channel * h_out;
+  for (i64 index = 0; index < nrows; index++) {
+    int pn = index / h_out / channel;
+    int pg = pn % npart;
+    for (int pwb = 0; pwb < 2; pwb++)
+      for (int pwa = 0; pwa < pad; pwa++) {
+        int wl = hindex[pg];
+        int qw = pwb * (wl + pad) + pwa;
+        i64 base = index * w_out;
+        out[base + (qw - pad + wl) % wl + pad] += out[base + qw];
+        out[base + qw] = 0.f;
+      }
+  }
+  /* pseudo_pad_backward_kernel (:127-155): interior, zero in the dead columns */
+  const i64 nin = (i64)num * channel * height * width;
+  for (i64 index = 0; index < nin; index++) {
+    int pw = index % width;
+    i64 ps = index / width / height; /* tile-batch * channel + channel */
+    int ph = (index / width) % height;
+    int pg = (ps / channel) % npart;
+    bottom_diff[index] = pw < hindex[pg] ? out[(ps * h_out + ph + pad) * w_out + pw + pad] : 0.f;
+  }
+  /* the inverse-list gather, as the scatter it stands for: every halo entry (tg, tl, tp, tw)
+   * hands its gradient to its two source columns with weights t and 1 - t */
+  const i64 astride = (i64)h_out * w_out, astride_out = (i64)npart * channel * astride;
+  const i64 bstride = (i64)height * width, bstride_out = (i64)npart * channel * bstride;
+  const int nentries = npart * 2 * pad * width;
+  for (int tn = 0; tn < num / npart; tn++)
+    for (int pc = 0; pc < channel; pc++)
+      for (int e = 0; e < nentries; e++) {
+        int tw = e % width;
+        int tg = e / width / pad / 2;
+        if (tw >= hindex[tg]) continue;
+        int qg = hindex2[e / width];
+        float g = out[dstoff[e] + tn * astride_out + pc * astride + tw + pad];
+        i64 q = srcoff[e] + tn * bstride_out + pc * bstride;
+        bottom_diff[q + pcol[e]] += g * pt[e];
+        bottom_diff[q + (pcol[e] + 1) % hindex[qg]] += g * (1 - pt[e]);
+      }
+  free(out);
+}
+
+/* ---- context_reshape_cuda.cu:63-72 ------------------------------------------------------ */
+void orc_context_reshape_backward(float *bottom, const float *top, int num, int channel, int height, int width,
+                                  int cpg) {
+  const int inner_size = height * width;
+  const i64 nthreads = (i64)num * channel * inner_size;
+  for (i64 index = 0; index < nthreads; index++) {
+    i64 pn = index / inner_size / channel;
+    int pc = (index / inner_size) % channel;
+    int ps = index % inner_size;
+    i64 tidx = (pn * inner_size * channel / cpg + (i64)(pc / cpg) * inner_size + ps) * cpg + pc % cpg;
+    bottom[index] = top[tidx];
+  }
+}

@@ -180,6 +180,20 @@ class PseudoContextOp(_TileContext):
             self._cache[key] = tuple(self._upload(a, like) for a in (src_tile, src_row, col, wgt))
         return self._cache[key]
 
+    def pad_reverse_tables(self, height, width, pad, like):
+        """reverse CSR of pad_tables for PseudoPadOp.backward (pconv_host_pad_reverse)"""
+        key = ("padrev", int(height), int(width), int(pad), like.device)
+        if key not in self._cache:
+            wh = self.widths_host(height, width)
+            start = np.zeros(self.npart_ * height * width + 1, np.int32)
+            cap = 4 * self.npart_ * pad * width
+            dst = np.zeros(cap, np.int32)
+            wgt = np.zeros(cap, np.float32)
+            call("pconv_host_pad_reverse", _np_ptr(wh), self.npart_, height, width, pad, _np_ptr(start), _np_ptr(dst),
+                 _np_ptr(wgt))
+            self._cache[key] = tuple(self._upload(a, like) for a in (start, dst, wgt))
+        return self._cache[key]
+
 
 class PseudoEntropyContextOp(_TileContext):
     """PCONV.PseudoEntropyContextOp (main.cpp:109-113).  Only the geometry used by
@@ -274,11 +288,17 @@ class ContextReshapeOp(_Op):
         _require_gpu(x, "ContextReshapeOp")
         n, c, h, w = x.shape
         out = self._out(0, (n * h * w * self.ngroup_, c // self.ngroup_), x)
+        self._fwd_shape = (n, c, h, w)
         call("pconv_context_reshape", _ptr(x), _ptr(out), n, c, h, w, self.ngroup_, _stream(x.device))
         return [out]
 
     def backward(self, grad):
-        raise NotImplementedError("ContextReshapeOp.backward: training path is out of scope (SURVEY 2.1)")
+        """(n*g*h*w, cpg) -> (n, g*cpg, h, w): the inverse permutation (context_reshape_cuda.cu:63-95)"""
+        _require_gpu(grad, "ContextReshapeOp.backward")
+        n, c, h, w = self._fwd_shape
+        out = self._out(1, (n, c, h, w), grad)
+        call("pconv_context_reshape_backward", _ptr(grad), _ptr(out), n, c, h, w, self.ngroup_, _stream(grad.device))
+        return [out]
 
 
 class EntropyGmmOp(_Op):
@@ -305,7 +325,11 @@ class EntropyGmmOp(_Op):
         return [loss]
 
     def backward(self, grad):
-        raise NotImplementedError("EntropyGmmOp.backward: training path is out of scope (SURVEY 2.1)")
+        """the per-row derivatives the forward kernel left in the op's buffers, times the
+        incoming gradient (entropy_gmm_cuda.cu:95-127): [d weight, d delta, d mean, d label]"""
+        _require_gpu(grad, "EntropyGmmOp.backward")
+        g = grad.reshape(-1, 1)
+        return [self._top[1] * g, self._top[2] * g, self._top[3] * g, self._top[4] * g]
 
 
 class MaskConstrainOp(_Op):
@@ -365,7 +389,17 @@ class SphereSliceOp(_SphereResample):
         return [out]
 
     def backward(self, grad):
-        raise NotImplementedError("SphereSliceOp.backward: training path is out of scope (SURVEY 2.1)")
+        """grad of the tile stack -> grad of the ERP image: the transpose of the 4-tap resampling
+        (sphere_slice_cuda.cu:191-244)"""
+        _require_gpu(grad, "SphereSliceOp.backward")
+        tn, c, hp, wp = grad.shape
+        p = self.pad_
+        n, h, w = tn // self.npart_, (hp - 2 * p) * self.npart_, wp - 2 * p
+        wd, col, coef = self._tables("pconv_host_slice_taps", h, w, grad)
+        out = self._out(1, (n, c, h, w), grad)
+        call("pconv_sphere_slice_backward", _ptr(grad), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+             self.npart_, p, _stream(grad.device))
+        return [out]
 
 
 class SphereUsliceOp(_SphereResample):
@@ -386,7 +420,17 @@ class SphereUsliceOp(_SphereResample):
         return [out]
 
     def backward(self, grad):
-        raise NotImplementedError("SphereUsliceOp.backward: training path is out of scope (SURVEY 2.1)")
+        """grad of the ERP image -> grad of the (padded) tile stack, zero outside the valid
+        interior (sphere_uslice_cuda.cu:128-200)"""
+        _require_gpu(grad, "SphereUsliceOp.backward")
+        n, c, hh, w = grad.shape
+        p = self.pad_
+        h = hh // self.npart_
+        wd, col, coef = self._tables("pconv_host_uslice_taps", hh, w, grad)
+        out = self._out(1, (n * self.npart_, c, h + 2 * p, w + 2 * p), grad)
+        call("pconv_sphere_uslice_backward", _ptr(grad), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+             self.npart_, p, _stream(grad.device))
+        return [out]
 
 
 class PseudoPadOp(_Op):
@@ -427,7 +471,18 @@ class PseudoPadOp(_Op):
         return buf if d == 0 else buf[:, :, d:-d, d:-d]
 
     def backward(self, grad):
-        raise NotImplementedError("PseudoPadOp.backward: training path is out of scope (SURVEY 2.1)")
+        """grad (tn, c, h+2p, w+2p) -> (tn, c, h, w): interior + folded wrap columns + the halo
+        entries interpolated from each element (pseudo_pad.cu:127-235)"""
+        _require_gpu(grad, "PseudoPadOp.backward")
+        tn, c, hp, wp = grad.shape
+        p = self.pad_
+        h, w = hp - 2 * p, wp - 2 * p
+        wd = self.ctx_.widths(h, w, grad)
+        rs, rd, rw = self.ctx_.pad_reverse_tables(h, w, p, grad)
+        out = self._out(1, (tn, c, h, w), grad)
+        call("pconv_pseudo_pad_backward", _ptr(grad), _ptr(out), _ptr(wd), _ptr(rs), _ptr(rd), _ptr(rw), tn, c, h, w,
+             p, self.npart_, _stream(grad.device))
+        return [out]
 
 
 class PseudoFillOp(_Op):

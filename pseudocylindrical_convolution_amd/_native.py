@@ -40,6 +40,12 @@ _HIP_SIGNATURES = {
     "pconv_project": [P, P, P, I, I, I, I, I, I, I, I, P],
     "pconv_context_reshape": [P, P, I, I, I, I, I, P],
     "pconv_mask_constrain": [P, I, I, I, I, I, P],
+    # backward of the linear geometry ops (training path)
+    "pconv_context_reshape_backward": [P, P, I, I, I, I, I, P],
+    "pconv_sphere_slice_backward": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "pconv_sphere_uslice_backward": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "pconv_host_pad_reverse": [P, I, I, I, I, P, P, P],
+    "pconv_pseudo_pad_backward": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_gmm_loss": [P, P, P, P, P, P, P, P, P, I, I, P],
     "pconv_conv_packed_size": [I, I, I, P, P],
     "pconv_conv_pack_weight": [P, P, I, I, I, P],

@@ -797,7 +797,11 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   // slab serves several positions.  PCONV_EE_BLOCK (threads per workgroup: 256 / 512 / 1024)
   // and PCONV_EE_PPW (positions a wave walks) are tuning knobs.
   static const int block = getenv("PCONV_EE_BLOCK") ? atoi(getenv("PCONV_EE_BLOCK")) : kConvBlock;
-  static const int ppw = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : kPosPerWave;
+  // measured (MI355X, 4096x2048, decode of 1 / 2 / 4 / 8 frames in two groups): 4 positions
+  // per wave 106 / 122 / 163 / 230 ms, 2 positions 99 / 117 / 159 / 257 ms; 512- and
+  // 1024-thread workgroups are slower at every batch size
+  static const int ppw_env = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : 0;
+  const int ppw = ppw_env > 0 ? ppw_env : (g->nimg <= 1 ? 2 : kPosPerWave);
   const int waves = block / kWave;
   int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;

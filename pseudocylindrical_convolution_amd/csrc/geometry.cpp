@@ -174,6 +174,50 @@ extern "C" int pconv_host_pad_table(const int32_t *widths, int npart, int height
   return PCONV_OK;
 }
 
+// Reverse of pconv_host_pad_table for PseudoPad's backward: CSR over the interior elements
+// (tile*height + row)*width + col of ONE channel plane set -> the halo entries that read the
+// element, as (destination tile << 24 | padded row*width + column, weight).  rev_start has
+// npart*height*width + 1 entries; rev_dst / rev_wgt hold at most 2 * npart*2*pad*width.
+// Returns the number of records, or a negative status.
+extern "C" int pconv_host_pad_reverse(const int32_t *widths, int npart, int height, int width, int pad,
+                                      int32_t *rev_start, int32_t *rev_dst, float *rev_wgt) {
+  PCONV_REQUIRE(widths && rev_start && rev_dst && rev_wgt, "pad_reverse: null pointer");
+  PCONV_REQUIRE(pad > 0 && height > 0 && (long long)(height + 2 * pad) * width < (1 << 24) && npart <= 128,
+                "pad_reverse: bad pad/height");
+  const size_t n = (size_t)npart * 2 * pad * width;
+  std::vector<int32_t> st(npart * 2 * pad), sr(npart * 2 * pad), col(n);
+  std::vector<float> wgt(n);
+  int rc = pconv_host_pad_table(widths, npart, height, width, pad, st.data(), sr.data(), col.data(), wgt.data());
+  if (rc < 0) return rc;
+  const size_t keys = (size_t)npart * height * width;
+  std::vector<std::vector<std::pair<int32_t, float>>> lists(keys);
+  for (int t = 0; t < npart; t++)
+    for (int side = 0; side < 2; side++)
+      for (int r = 0; r < pad; r++) {
+        const int e = (t * 2 + side) * pad + r;
+        const int prow = side ? height + pad + r : r;  // padded row of the halo entry
+        const int s_t = st[e], s_r = sr[e], ws = widths[s_t];
+        for (int i = 0; i < widths[t]; i++) {
+          const size_t k = (size_t)e * width + i;
+          const int c0 = col[k], c1 = (c0 + 1) % ws;
+          const int32_t dst = (t << 24) | (prow * width + i);
+          lists[((size_t)s_t * height + s_r) * width + c0].push_back({dst, wgt[k]});
+          lists[((size_t)s_t * height + s_r) * width + c1].push_back({dst, 1.f - wgt[k]});
+        }
+      }
+  int total = 0;
+  for (size_t k = 0; k < keys; k++) {
+    rev_start[k] = total;
+    for (auto &p : lists[k]) {
+      rev_dst[total] = p.first;
+      rev_wgt[total] = p.second;
+      total++;
+    }
+  }
+  rev_start[keys] = total;
+  return total;
+}
+
 extern "C" int pconv_host_wavefront(const int32_t *widths, int npart, int height, int width,
                                     int32_t *order, int32_t *plane_start) {
   PCONV_REQUIRE(widths && order && plane_start, "wavefront: null pointer");

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round 2 validation + evidence: full GPU suite, smoke, headline bench, config #3, rocprofv3
+# kernel stats of both, PMC passes (separate runs) summarised per kernel.
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=5 > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
+grep -q "Memory access fault" $O/pytest_gpu.log && exit 1
+tail -8 $O/pytest_gpu.log
+python __graft_entry__.py --smoke 2>&1 | tail -1
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err || { tail -30 $O/bench_n1.err; exit 1; }
+cat $O/bench_n1.json
+python bench.py --mode analysis --steps 5 --warmup 2 > $O/analysis_1024x2048.json 2> $O/analysis.err || { tail -30 $O/analysis.err; exit 1; }
+cut -c1-400 $O/analysis_1024x2048.json
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_bench /tmp/prof_an
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 1 --warmup 0 --prime 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err || tail -5 $O/bench_under_rocprof.err
+cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+PCONV_BENCH_TABLE=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_an -- python3 $R/bench.py --mode analysis --steps 5 --warmup 2 > $O/analysis_under_rocprof.json 2> $O/analysis_under_rocprof.err || tail -5 $O/analysis_under_rocprof.err
+cp $(find /tmp/prof_an -name "*kernel_stats.csv" | head -1) $O/analysis_kernel_stats.csv
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); rm -rf /tmp/pmc_b_$i
+  PCONV_BENCH_TABLE=1 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_b_$i -- python3 $R/bench.py --frames-per-gpu 2 --steps 1 --warmup 0 --prime 1 --no-cpu-baseline --no-check > $O/pmc_pass_$i.json 2> $O/pmc_pass_$i.err || { tail -5 $O/pmc_pass_$i.err; }
+done
+python3 $R/tools/summarise_pmc.py $O/bench_pmc.json /tmp/pmc_b_1 /tmp/pmc_b_2 /tmp/pmc_b_3 /tmp/pmc_b_4 --bench-json $O/pmc_pass_1.json
+echo done

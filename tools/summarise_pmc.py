@@ -48,6 +48,19 @@ def main():
         elif args[i] == "--trace":
             trace = args[i + 1]
             i += 2
+        elif args[i] == "--bench-json":
+            # the JSON line bench.py printed in one of the passes (PCONV_BENCH_TABLE=1): algorithmic
+            # flops per launch of every conv kernel, averaged over its launches
+            with open(args[i + 1]) as f:
+                line = [l for l in f.read().splitlines() if l.startswith("{")][-1]
+            per = {}
+            for r in json.loads(line).get("roofline_table", []):
+                d = per.setdefault(r["kernel"], [0.0, 0])
+                d[0] += r["gflop_per_launch"] * 1e9 * r["launches"]
+                d[1] += r["launches"]
+            for k, (fl, n) in per.items():
+                flops[k.replace(", ", ", ")] = fl / n
+            i += 2
         else:
             dirs.append(args[i])
             i += 1
