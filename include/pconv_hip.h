@@ -203,6 +203,14 @@ int pconv_pseudo_pad_backward(const float *gout, float *gin, const int32_t *widt
                               const int32_t *rev_start, const int32_t *rev_dst, const float *rev_wgt,
                               int tn, int c, int h, int w, int pad, int npart, void *stream);
 
+/* PseudoQuantOp.backward (pseudo_quant_cuda.cu:197-311).  x / val / idx: input and the two outputs
+ * of the forward call, level_tab: the table that call filled; g_val / g_idx (may be NULL): gradients
+ * of the outputs.  g_in (tn,c,h,w), g_weight (c,levels); bins: scratch of c*levels floats. */
+int pconv_quant_backward(const float *x, const float *val, const float *idx, const float *g_val,
+                         const float *g_idx, const float *level_tab, float *g_in, float *g_weight,
+                         float *bins, const int32_t *widths, float top_alpha, int tn, int c, int h,
+                         int w, int levels, int npart, void *stream);
+
 /* MaskConstrainOp.forward, in place on a conv weight (nout, cin, k, k)
  * (mask_constrain_cuda.cu:19-88); constrain in {1,2,5,6} */
 int pconv_mask_constrain(float *weight, int nout, int cin, int k, int ngroup, int constrain,

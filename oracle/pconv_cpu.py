@@ -391,6 +391,7 @@ class PseudoQuantOp(_Base):
                  timeit=False):
         super().__init__(device, timeit)
         self.channel_, self.bin_num_, self.npart_, self.ntop_ = channel, bin_num, npart, ntop
+        self.top_alpha_ = top_alpha
         self.weight_decay_, self.mod_, self.iter_ = weight_decay, check_iters, 0
         self.ctx_ = _ctx(addr)
 
@@ -430,7 +431,21 @@ class PseudoQuantOp(_Base):
         lib().orc_quant_forward(_p(x), _p(weight.detach().contiguous()), _p(tab), _p(quant), _p(val), _p(idx),
                                 _p(self.count_data_), _p(hidx), I(num), I(c), I(h), I(w), I(self.bin_num_),
                                 I(self.npart_))
+        self.tab_, self.quant_, self.top_alpha_used_ = tab, quant, None
         return [val, idx] if idx is not None else [val]
+
+    def backward(self, grads, x, out):
+        # pseudo_quant_cuda.cu:197-311
+        num, c, h, w = x.shape
+        hidx = self.ctx_.hindex(h, w)
+        g_val = grads[0].contiguous()
+        g_idx = grads[1].contiguous() if self.ntop_ > 1 and len(grads) > 1 and grads[1] is not None else None
+        g_in = self._top("g_in", x.shape)
+        g_w = self._top("g_w", (c, self.bin_num_))
+        lib().orc_quant_backward(_p(x.contiguous()), _p(out.contiguous()), _p(self.quant_), _p(g_val), _p(g_idx),
+                                 _p(self.tab_), _p(g_in), _p(g_w), _p(hidx), F(self.top_alpha_), I(num), I(c), I(h),
+                                 I(w), I(self.bin_num_), I(self.npart_))
+        return [g_in, g_w, self.count_data_]
 
 
 class PseudoDQuantOp(_Base):

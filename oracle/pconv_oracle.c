@@ -1226,3 +1226,56 @@ void orc_context_reshape_backward(float *bottom, const float *top, int num, int 
     bottom[index] = top[tidx];
   }
 }
+
+/* ---- pseudo_quant_cuda.cu:197-311: quant_backward_cuda, kernel by kernel ------------------- */
+void orc_quant_backward(const float *bottom_data, const float *top_data, const int *quant, const float *top_diff0,
+                        const float *top_diff1, const float *weight, float *bottom_diff0, float *bottom_diff1,
+                        const int *hindex, float alpha, int num, int channels, int height, int width, int levels,
+                        int npart) {
+  const int inner_shape = height * width;
+  const i64 n = (i64)num * channels * inner_shape;
+  const i64 stride = (i64)inner_shape * channels;
+  /* bottom_diff_[0] = top_data - bottom_data; pseudo_constr_kernel */
+  float *err = (float *)malloc(sizeof(float) * (size_t)n);
+  for (i64 i = 0; i < n; i++) {
+    int pw = i % width;
+    int pg = (i / stride) % npart;
+    err[i] = pw >= hindex[pg] ? 0.f : top_data[i] - bottom_data[i];
+  }
+  /* pseudo_quant_single_gpu_backward_kernel: every element adds its error to levels 0..quant */
+  for (int i = 0; i < channels * levels; i++) bottom_diff1[i] = 0.f;
+  for (i64 i = 0; i < n; i++) {
+    int pc = (i / inner_shape) % channels;
+    for (int j = 0; j <= quant[i]; j++) bottom_diff1[pc * levels + j] += err[i];
+  }
+  /* pseudo_quant_cal_weight_diff_kernel */
+  for (int i = 0; i < channels * levels; i++)
+    if (i % levels != 0) bottom_diff1[i] = bottom_diff1[i] * weight[i];
+  /* bottom_diff_[0].copy_(top_diff[0]); pseudo_quant_top_diff_kernel; pseudo_constr_kernel */
+  for (i64 i = 0; i < n; i++) {
+    float g = top_diff0[i];
+    if (top_diff1) {
+      int tc = (i / inner_shape) % channels;
+      float beta = 1.0;
+      if (top_data[i] < bottom_data[i]) {
+        beta = quant[i] < levels - 1 ? weight[tc * levels + quant[i] + 1] : 10000;
+      } else if (top_data[i] > bottom_data[i]) {
+        beta = quant[i] > 0 ? weight[tc * levels + quant[i]] : 10000;
+      } else {
+        if (quant[i] == 0) {
+          beta = weight[tc * levels + quant[i] + 1];
+        } else if (quant[i] < levels - 1) {
+          beta = (weight[tc * levels + quant[i]] + weight[tc * levels + quant[i] + 1]) / 2.0;
+        } else {
+          beta = weight[tc * levels + quant[i]];
+        }
+      }
+      if (beta < 0.001) beta = 0.001;
+      g = g + alpha * top_diff1[i] / beta;
+    }
+    int pw = i % width;
+    int pg = (i / stride) % npart;
+    bottom_diff0[i] = pw >= hindex[pg] ? 0.f : g;
+  }
+  free(err);
+}

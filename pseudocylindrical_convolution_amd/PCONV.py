@@ -537,6 +537,7 @@ class PseudoQuantOp(_Op):
         super().__init__(device, timeit)
         self.channel_, self.bin_num_, self.npart_ = int(channel), int(bin_num), int(npart)
         self.ntop_ = int(ntop)
+        self.top_alpha_ = float(top_alpha)
         self.weight_decay_, self.mod_ = float(weight_decay), int(check_iters)
         self.iter_ = 0
         self.count_data_ = None
@@ -575,7 +576,7 @@ class PseudoQuantOp(_Op):
         wd = self.ctx_.widths(h, w, x)
         tab = self._out("tab", (c, self.bin_num_), x)
         val = self._out(0, x.shape, x)
-        idx = self._out(1, x.shape, x) if self.ntop_ > 1 else None
+        idx = self._out(1, x.shape, x)  # kept for backward even when only the value is returned
         # per-call histogram of the levels hit, -1 per valid element: the op's own
         # count_data_ (pseudo_quant_cuda.cu:12,64,83,167), zeroed on every call; the
         # reference hands it to autograd as the "gradient" of the module's `count`
@@ -585,10 +586,27 @@ class PseudoQuantOp(_Op):
              _ptr(wd), tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
         if train:
             self.iter_ += 1
-        return [val, idx] if idx is not None else [val]
+        return [val, idx] if self.ntop_ > 1 else [val]
 
     def backward(self, grads, x, out):
-        raise NotImplementedError("PseudoQuantOp.backward: training path is out of scope (SURVEY 2.1)")
+        """[g_val(, g_idx)], the forward's input and value output -> [g_x, g_weight, count_data_]
+        (pseudo_quant_cuda.cu:197-311): straight-through for the value, the index gradient scaled
+        by the local level width, the quantisation error summed into the levels at or below each
+        element's level; the per-call histogram is what the reference hands back for `count`."""
+        _require_gpu(x, "PseudoQuantOp.backward")
+        tn, c, h, w = x.shape
+        if self.count_data_ is None or 1 not in self._top or tuple(self._top[0].shape) != tuple(x.shape):
+            raise PconvError("PseudoQuantOp.backward: no matching forward call")
+        g_val = grads[0].contiguous()
+        g_idx = grads[1].contiguous() if self.ntop_ > 1 and len(grads) > 1 and grads[1] is not None else None
+        wd = self.ctx_.widths(h, w, x)
+        g_in = self._out("g_in", x.shape, x)
+        g_w = self._out("g_w", (c, self.bin_num_), x)
+        bins = self._out("bins", (c, self.bin_num_), x)
+        call("pconv_quant_backward", _ptr(x), _ptr(out), _ptr(self._top[1]), _ptr(g_val), _ptr(g_idx),
+             _ptr(self._top["tab"]), _ptr(g_in), _ptr(g_w), _ptr(bins), _ptr(wd), self.top_alpha_, tn, c, h, w,
+             self.bin_num_, self.npart_, _stream(x.device))
+        return [g_in, g_w, self.count_data_]
 
 
 class PseudoDQuantOp(_Op):

@@ -237,6 +237,26 @@ class PseudoGDNV2(nn.Module):
         return inputs * norm_ if self.inverse else inputs / norm_
 
 
+class _QuantCall(torch.autograd.Function):
+    """autograd bridge of the quantiser (reference: PseudoContextV2.py:218-239): backward hands
+    back the input gradient, the level-table gradient and the per-call histogram for `count`"""
+
+    @staticmethod
+    def forward(ctx, module, x, weight, count, training):
+        op = module.native(x)
+        outs = op.forward(x, weight, count, training)
+        ctx.op = op
+        ctx.save_for_backward(x, outs[0])
+        return outs[0] if len(outs) == 1 else (outs[0], outs[1])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, out = ctx.saved_tensors
+        g = [t.contiguous() if t is not None else torch.zeros_like(x) for t in grads]
+        gx, gw, gc = ctx.op.backward(g, x, out)
+        return None, gx, gw, gc.clone().detach(), None
+
+
 class PseudoQUANTV2(BaseOpModule):
     """learned 8-level per-channel quantiser (reference: PseudoContextV2.py:241-255)."""
 
@@ -257,6 +277,8 @@ class PseudoQUANTV2(BaseOpModule):
     def forward(self, x):
         if not x.is_contiguous():
             x = x.contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _QuantCall.apply(self, x, self.weight, self.count, self.training)
         outs = self.native(x).forward(x, self.weight, self.count, self.training)
         return outs[0] if len(outs) == 1 else (outs[0], outs[1])
 

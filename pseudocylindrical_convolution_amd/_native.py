@@ -46,6 +46,7 @@ _HIP_SIGNATURES = {
     "pconv_sphere_uslice_backward": [P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_host_pad_reverse": [P, I, I, I, I, P, P, P],
     "pconv_pseudo_pad_backward": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "pconv_quant_backward": [P, P, P, P, P, P, P, P, P, P, F, I, I, I, I, I, I, P],
     "pconv_gmm_loss": [P, P, P, P, P, P, P, P, P, I, I, P],
     "pconv_conv_packed_size": [I, I, I, P, P],
     "pconv_conv_pack_weight": [P, P, I, I, I, P],

@@ -717,8 +717,13 @@ int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, i
       raised.fetch_or(bit, std::memory_order_release);
     }
   }
-  // PCONV_CONV_XCD=0 keeps the plain order (A/B measurements)
-  static const bool xcd_order = !(getenv("PCONV_CONV_XCD") && atoi(getenv("PCONV_CONV_XCD")) == 0);
+  // PCONV_CONV_XCD=1 turns the XCD-grouped order on.  Measured on the analysis transform of a
+  // 4096x2048 frame (same box, alternating runs): HBM reads of the 3x3 192-cout kernel 1.46 GB per
+  // launch instead of 1.82 GB (FETCH_SIZE, profiles/), but 59.3-59.5 ms per frame instead of
+  // 58.4-58.5: the kernel is not bandwidth-bound (0.3 TB/s) and the grouped order starts the
+  // stripes of a tile one after the other on an XCD.  Off by default; the order is kept as the
+  // measured alternative.
+  static const bool xcd_order = getenv("PCONV_CONV_XCD") && atoi(getenv("PCONV_CONV_XCD")) == 1;
   const int xcd_group = (xcd_order && KS == 3) ? cblocks * tiles_r : 0;  // 1x1 tiles share no rows
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, stream, in, wp, out, cin, h, w, cout,
                      cout_pad, ho, wo, tiles_r, tiles_c, cblocks, xcd_group, vin, vout, ep);

@@ -233,6 +233,64 @@ __global__ __launch_bounds__(kBlock) void gmm_loss_kernel(
   }
 }
 
+// PseudoQuantOp.backward (pseudo_quant_cuda.cu:197-311), one pass over the activation:
+//   g_in = g_val + alpha * g_idx / beta   (straight-through for the value, the index output's
+//          gradient scaled by the width of the level interval the input sits in), zero in the
+//          dead columns;
+//   bins[c][q] += val - x  for the element's level q (the reference adds it to levels 0..q with
+//          q + 1 atomics; the suffix sum over q is taken by quant_weight_grad_kernel below).
+__global__ __launch_bounds__(kBlock) void quant_backward_kernel(
+    const float *__restrict__ x, const float *__restrict__ val, const float *__restrict__ idx,
+    const float *__restrict__ g_val, const float *__restrict__ g_idx, const float *__restrict__ tab,
+    float *__restrict__ g_in, float *__restrict__ bins, const int32_t *__restrict__ widths, float alpha, int c,
+    int hw, int w, int levels, int npart, long long total) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int pw = (int)(i % w);
+    const long long plane = i / hw;
+    const int pc = (int)(plane % c);
+    const int pg = (int)((plane / c) % npart);
+    float g = 0.f;
+    if (pw < widths[pg]) {
+      const float xv = x[i], tv = val[i];
+      const int q = (int)idx[i];
+      atomicAdd(bins + pc * levels + q, tv - xv);
+      g = g_val[i];
+      if (g_idx) {
+        const float *lv = tab + pc * levels;
+        float beta;
+        if (tv < xv) {
+          beta = q < levels - 1 ? lv[q + 1] : 10000.f;
+        } else if (tv > xv) {
+          beta = q > 0 ? lv[q] : 10000.f;
+        } else if (q == 0) {
+          beta = lv[1];
+        } else if (q < levels - 1) {
+          beta = (lv[q] + lv[q + 1]) / 2.0;
+        } else {
+          beta = lv[q];
+        }
+        if (beta < 0.001) beta = 0.001;
+        g = g + alpha * g_idx[i] / beta;
+      }
+    }
+    g_in[i] = g;
+  }
+}
+
+// weight_diff[c][j] = sum over levels q >= j of bins[c][q], times d level / d weight
+// (exp(w) = the level table entry for j > 0, 1 for j = 0) (pseudo_quant_cuda.cu:205-233)
+__global__ void quant_weight_grad_kernel(const float *__restrict__ bins, const float *__restrict__ tab,
+                                         float *__restrict__ g_w, int nch, int levels) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= nch) return;
+  float acc = 0.f;
+  for (int j = levels - 1; j >= 0; j--) {
+    acc += bins[ch * levels + j];
+    g_w[ch * levels + j] = j ? acc * tab[ch * levels + j] : acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int pconv_quant(const float *x, const float *weight, float *level_tab, float *out_val,
@@ -307,5 +365,27 @@ extern "C" int pconv_gmm_loss(const float *weight, const float *delta, const flo
                      as_stream(stream), weight, delta, mean, label, loss, d_weight, d_delta, d_mean,
                      d_label, m, ng);
   PCONV_LAUNCH_CHECK("gmm_loss");
+  return PCONV_OK;
+}
+
+// PseudoQuantOp.backward: x, val, idx = the forward's input and outputs; level_tab = the table the
+// forward left (w[c,0], exp(w[c,j])); g_idx may be null (ntop == 1).  bins: scratch (c*levels).
+extern "C" int pconv_quant_backward(const float *x, const float *val, const float *idx, const float *g_val,
+                                    const float *g_idx, const float *level_tab, float *g_in, float *g_weight,
+                                    float *bins, const int32_t *widths, float top_alpha, int tn, int c, int h,
+                                    int w, int levels, int npart, void *stream) {
+  PCONV_REQUIRE(x && val && idx && g_val && level_tab && g_in && g_weight && bins && widths,
+                "quant_backward: null pointer");
+  PCONV_REQUIRE(tn > 0 && c > 0 && h > 0 && w > 0 && levels > 1, "quant_backward: bad shape");
+  if (hipMemsetAsync(bins, 0, (size_t)c * levels * sizeof(float), as_stream(stream)) != hipSuccess) {
+    pconv_set_error("quant_backward: memset failed");
+    return PCONV_ELAUNCH;
+  }
+  const long long total = (long long)tn * c * h * w;
+  hipLaunchKernelGGL(quant_backward_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x, val, idx,
+                     g_val, g_idx, level_tab, g_in, bins, widths, top_alpha, c, h * w, w, levels, npart, total);
+  hipLaunchKernelGGL(quant_weight_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), bins,
+                     level_tab, g_weight, c, levels);
+  PCONV_LAUNCH_CHECK("quant_backward");
   return PCONV_OK;
 }
