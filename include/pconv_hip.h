@@ -203,6 +203,12 @@ int pconv_pseudo_pad_backward(const float *gout, float *gin, const int32_t *widt
                               const int32_t *rev_start, const int32_t *rev_dst, const float *rev_wgt,
                               int tn, int c, int h, int w, int pad, int npart, void *stream);
 
+/* ProjectsOp.backward (projects_cuda.cu:257-329): gout (n*nview, c, h_out, w_out) -> gin and count
+ * (n, c, height, width); count = the sampling weights each source pixel received. */
+int pconv_project_backward(const float *gout, const float *tf, float *gin, float *count, int n, int c,
+                           int height, int width, int nview, int h_out, int w_out, int nearest,
+                           void *stream);
+
 /* PseudoQuantOp.backward (pseudo_quant_cuda.cu:197-311).  x / val / idx: input and the two outputs
  * of the forward call, level_tab: the table that call filled; g_val / g_idx (may be NULL): gradients
  * of the outputs.  g_in (tn,c,h,w), g_weight (c,levels); bins: scratch of c*levels floats. */
@@ -370,6 +376,12 @@ long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e);
 int pconv_ee_steps(const pconv_entropy_engine *e);
 /* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */
 int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream);
+/* the same in two halves: begin queues the GPU part IN `stream` and starts the host thread that
+ * arithmetic-codes the frames as their tables arrive, then returns; end joins that thread.
+ * `symbols` must stay alive until end.  Between the two the caller may queue other GPU work in
+ * `stream` (the transforms of the next frames): it runs while the CPU codes. */
+int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *stream);
+int pconv_ee_encode_end(pconv_entropy_engine *e, void *stream);
 const uint8_t *pconv_ee_stream(const pconv_entropy_engine *e, int img, size_t *nbytes);
 int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, const size_t *nbytes,
                     float *symbols_out, void *stream);

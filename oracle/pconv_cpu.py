@@ -485,7 +485,15 @@ class ProjectsOp(_Base):
         out = self._top(0, (n * self.nv_, c, self.h_out_, self.w_out_))
         lib().orc_projects_forward(_p(x), _p(self.tf[(h, w)]), _p(out), I(n), I(c), I(h), I(w), I(self.nv_),
                                    I(self.h_out_), I(self.w_out_), I(1 if self.near_ else 0))
+        self.shape_ = (n, c, h, w)
         return [out]
+
+    def backward(self, grad):
+        n, c, h, w = self.shape_
+        gin, cnt = self._top(1, (n, c, h, w)), self._top(2, (n, c, h, w))
+        lib().orc_projects_backward(_p(gin), _p(cnt), _p(self.tf[(h, w)]), _p(grad.contiguous()), I(n), I(c), I(h), I(w),
+                                    I(self.nv_), I(self.h_out_), I(self.w_out_), I(1 if self.near_ else 0))
+        return [gin, cnt]
 
 
 # -- entropy wavefront ops ------------------------------------------------------------

@@ -1279,3 +1279,43 @@ void orc_quant_backward(const float *bottom_data, const float *top_data, const i
   }
   free(err);
 }
+
+/* ---- projects_cuda.cu:257-329: backward of the viewport sampling (float atomics there) ------ */
+void orc_projects_backward(float *input, float *count, const float *tf, const float *output, int num, int channel,
+                           int hs, int ws, int nv, int h_out, int w_out, int nearest) {
+  const int inner_shape = h_out * w_out, out_shape = num * channel;
+  const i64 nin = (i64)out_shape * hs * ws;
+  for (i64 i = 0; i < nin; i++) input[i] = count[i] = 0.f;
+  const i64 nthreads = (i64)out_shape * inner_shape * nv;
+  for (i64 index = 0; index < nthreads; index++) {
+    /* index = (view * out_shape + plane) * inner_shape + pixel, as the forward kernel reads it */
+    int ps = index % inner_shape;
+    int tn = (index / inner_shape) % out_shape;
+    int tb = index / inner_shape / out_shape;
+    int base = tb * 2 * inner_shape;
+    if (nearest) {
+      int tw = (int)(floor(tf[base + 2 * ps] + 0.5)) % ws;
+      int th = (int)(floor(tf[base + 2 * ps + 1] + 0.5));
+      th = th >= hs ? hs - 1 : th;
+      input[((i64)tn * hs + th) * ws + tw] += output[index];
+      count[((i64)tn * hs + th) * ws + tw] += 1.f;
+    } else {
+      int tw = (int)(floor(tf[base + 2 * ps]));
+      int th = (int)(floor(tf[base + 2 * ps + 1]));
+      int pw = (tw + 1) % ws;
+      int ph = th + 1 >= hs ? hs - 1 : th + 1;
+      float tx = tf[base + 2 * ps] - tw;
+      float ty = tf[base + 2 * ps + 1] - th;
+      float ntx = 1. - tx;
+      float nty = 1. - ty;
+      input[((i64)tn * hs + th) * ws + tw] += ntx * nty * output[index];
+      count[((i64)tn * hs + th) * ws + tw] += ntx * nty;
+      input[((i64)tn * hs + th) * ws + pw] += tx * nty * output[index];
+      count[((i64)tn * hs + th) * ws + pw] += tx * nty;
+      input[((i64)tn * hs + ph) * ws + tw] += ntx * ty * output[index];
+      count[((i64)tn * hs + ph) * ws + tw] += ntx * ty;
+      input[((i64)tn * hs + ph) * ws + pw] += tx * ty * output[index];
+      count[((i64)tn * hs + ph) * ws + pw] += tx * ty;
+    }
+  }
+}

@@ -660,12 +660,22 @@ class ProjectsOp(_Op):
                  self.h_out_, self.w_out_, h, w, _np_ptr(tf))
             self._tf[key] = self._upload(tf, x)
         out = self._out(0, (n * self.nview_, c, self.h_out_, self.w_out_), x)
+        self._fwd_shape = (n, c, h, w)
         call("pconv_project", _ptr(x), _ptr(self._tf[key]), _ptr(out), n, c, h, w, self.nview_, self.h_out_,
              self.w_out_, int(self.near_), _stream(x.device))
         return [out]
 
     def backward(self, grad):
-        raise NotImplementedError("ProjectsOp.backward: training path is out of scope (SURVEY 2.1)")
+        """grad of the viewports -> [grad of the ERP image, sampling-weight count]
+        (projects_cuda.cu:257-329)"""
+        _require_gpu(grad, "ProjectsOp.backward")
+        n, c, h, w = self._fwd_shape
+        key = (h, w, grad.device)
+        gin = self._out(1, (n, c, h, w), grad)
+        cnt = self._out(2, (n, c, h, w), grad)
+        call("pconv_project_backward", _ptr(grad), _ptr(self._tf[key]), _ptr(gin), _ptr(cnt), n, c, h, w, self.nview_,
+             self.h_out_, self.w_out_, int(self.near_), _stream(grad.device))
+        return [gin, cnt]
 
 
 # ---------------------------------------------------------------------------

@@ -47,6 +47,7 @@ _HIP_SIGNATURES = {
     "pconv_host_pad_reverse": [P, I, I, I, I, P, P, P],
     "pconv_pseudo_pad_backward": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_quant_backward": [P, P, P, P, P, P, P, P, P, P, F, I, I, I, I, I, I, P],
+    "pconv_project_backward": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "pconv_gmm_loss": [P, P, P, P, P, P, P, P, P, I, I, P],
     "pconv_conv_packed_size": [I, I, I, P, P],
     "pconv_conv_pack_weight": [P, P, I, I, I, P],
@@ -68,6 +69,8 @@ _HIP_SIGNATURES = {
     "pconv_ee_set_layer": [P, I, P, P, P, P],
     "pconv_ee_steps": [P],
     "pconv_ee_encode": [P, P, P],
+    "pconv_ee_encode_begin": [P, P, P],
+    "pconv_ee_encode_end": [P, P],
     "pconv_ee_decode": [P, P, P, P, P],
 }
 

@@ -22,7 +22,6 @@ constexpr uint64_t kMinRange = (kMaxRange >> 2) + 2;
 constexpr uint64_t kMaxTotal = kMinRange;  // min(UINT64_MAX / kMaxRange, kMinRange)
 constexpr uint64_t kMask = kMaxRange - 1;
 constexpr uint64_t kTop = kMaxRange >> 1;
-constexpr uint64_t kSecond = kTop >> 1;
 
 inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
@@ -38,23 +37,19 @@ struct Total {
 class BitSink {
  public:
   void clear() {
-    bytes_.clear();
+    len_ = 0;
     acc_ = 0;
     fill_ = 0;
   }
-  // append the low `n` bits of v, most significant first (n <= 32)
-  void put(uint64_t v, int n) {
-    while (n > 0) {
-      int take = 8 - fill_;
-      if (take > n) take = n;
-      acc_ = (acc_ << take) | ((v >> (n - take)) & ((1u << take) - 1));
-      fill_ += take;
-      n -= take;
-      if (fill_ == 8) {
-        bytes_.push_back((uint8_t)acc_);
-        acc_ = 0;
-        fill_ = 0;
-      }
+  // append the low `n` bits of v, most significant first (n <= 32): a 64-bit accumulator,
+  // whole bytes leave it as soon as they are complete
+  inline void put(uint64_t v, int n) {
+    acc_ = (acc_ << n) | (v & ((1ull << n) - 1));
+    fill_ += n;  // < 8 + 32
+    if (len_ + 8 > bytes_.size()) bytes_.resize(bytes_.size() * 2 + 4096);
+    while (fill_ >= 8) {
+      fill_ -= 8;
+      bytes_[len_++] = (uint8_t)(acc_ >> fill_);
     }
   }
   void put_run(int bit, uint64_t count) {
@@ -68,11 +63,13 @@ class BitSink {
   void pad_to_byte() {
     if (fill_ != 0) put(0, 8 - fill_);
   }
-  const std::vector<uint8_t> &bytes() const { return bytes_; }
+  const uint8_t *data() const { return bytes_.data(); }
+  size_t size() const { return len_; }
 
  private:
   std::vector<uint8_t> bytes_;
-  uint32_t acc_ = 0;
+  size_t len_ = 0;
+  uint64_t acc_ = 0;
   int fill_ = 0;
 };
 
@@ -142,6 +139,13 @@ struct pconv_coder {
     const uint64_t new_high = low + tot.div(sym_high * range) - 1;
     low = new_low;
     high = new_high;
+    renormalise<kEncode>();
+    return 0;
+  }
+
+  // shift out what low and high have settled (ArithmeticCoder.cpp:52-69 / 117-150)
+  template <bool kEncode>
+  inline void renormalise() {
     // leading bits on which low and high agree leave the state
     const int agree = clz32((uint32_t)((low ^ high) & kMask));
     if (agree > 0) {
@@ -173,7 +177,35 @@ struct pconv_coder {
       low = (low << squeeze) & (kMask >> 1);
       high = ((high << squeeze) & (kMask >> 1)) | kTop | ((1ull << squeeze) - 1);
     }
-    return 0;
+  }
+
+  // ArithmeticDecoder::read for the codec's tables: 8 symbols, total 65536.  The textbook form
+  // divides ((offset + 1) * total - 1) by the range and binary-searches the table for the
+  // quotient; with q = that quotient, table[k] <= q  <=>  table[k] * range < (offset + 1) * total
+  // <=>  floor(table[k] * range / total) <= offset, so the symbol is the number of thresholds
+  // floor(table[k] * range >> 16), k = 1..7, that do not exceed the offset: eight independent
+  // multiplies and compares, no division, no data-dependent branch -- and the two thresholds
+  // around the symbol are exactly the new interval bounds of update().  Same symbols, same state.
+  inline int read_symbol_8x65536(const uint32_t *t) {
+    const uint64_t range = high - low + 1;
+    if (low >= high || range < kMinRange || range > kMaxRange)
+      return fail(PCONV_CODER_ESTATE, "Assertion error: Range out of range");
+    const uint64_t offset = code - low;
+    uint64_t thr[9];
+#pragma GCC unroll 9
+    for (int k = 0; k < 9; k++) thr[k] = ((uint64_t)t[k] * range) >> 16;
+    unsigned symbol = 0;
+#pragma GCC unroll 7
+    for (int k = 1; k < 8; k++) symbol += thr[k] <= offset;
+    if (t[symbol] == t[symbol + 1]) return fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
+    if (offset < thr[symbol] || thr[symbol + 1] <= offset) return fail(PCONV_CODER_EDESYNC, "Assertion error");
+    const uint64_t base = low;
+    low = base + thr[symbol];
+    high = base + thr[symbol + 1] - 1;
+    renormalise<false>();
+    if (code < low || code > high)
+      return fail(PCONV_CODER_EDESYNC, "Assertion error: Code out of range");
+    return (int)symbol;
   }
 
   // ArithmeticDecoder::read (ArithmeticCoder.cpp:82-115)
@@ -216,7 +248,8 @@ static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, 
   const int stride = ncode + 1;
   for (int i = 0; i < n; i++) {
     const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
-    int s = c->read_symbol(row, (uint32_t)ncode, row[ncode]);
+    const int s = (ncode == 8 && row[8] == 65536u) ? c->read_symbol_8x65536(row)
+                                                   : c->read_symbol(row, (uint32_t)ncode, row[ncode]);
     if (s < 0) return s;
     out[i] = (T)s;
   }
@@ -288,18 +321,18 @@ int pconv_coder_end_encoder(pconv_coder *c) {
   if (c->has_path) {
     FILE *f = fopen(c->path.c_str(), "wb");
     if (!f) return c->fail(PCONV_CODER_EIO, "cannot open output file");
-    const std::vector<uint8_t> &b = c->sink.bytes();
-    size_t wr = b.empty() ? 0 : fwrite(b.data(), 1, b.size(), f);
+    const size_t nb = c->sink.size();
+    size_t wr = nb ? fwrite(c->sink.data(), 1, nb, f) : 0;
     fclose(f);
-    if (wr != b.size()) return c->fail(PCONV_CODER_EIO, "short write");
+    if (wr != nb) return c->fail(PCONV_CODER_EIO, "short write");
   }
   return 0;
 }
 
 const uint8_t *pconv_coder_bytes(const pconv_coder *c, size_t *nbytes) {
   if (!c) return nullptr;
-  if (nbytes) *nbytes = c->sink.bytes().size();
-  return c->sink.bytes().data();
+  if (nbytes) *nbytes = c->sink.size();
+  return c->sink.data();
 }
 
 static int begin_decode(pconv_coder *c, const uint8_t *p, size_t n) {

@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -191,6 +192,12 @@ struct pconv_entropy_engine {
   size_t sym_per_img = 0, max_len = 0;
   std::vector<std::vector<uint8_t>> streams;
   std::vector<pconv_coder *> coders;
+  // encode in flight (pconv_ee_encode_begin / _end)
+  std::thread enc_thread;
+  std::atomic<int> enc_status{0};
+  std::vector<std::string> enc_errors;
+  std::chrono::steady_clock::time_point enc_begin;
+  double enc_wait = 0, enc_coder = 0;
 
   size_t ctx_elems(int n) const { return (size_t)n * npart * ngroup * (h + 2 * kPad) * (w + 2 * kPad); }
   size_t act_elems(int l, int n) const {
@@ -589,6 +596,7 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
 
 void pconv_ee_destroy(pconv_entropy_engine *e) {
   if (!e) return;
+  if (e->enc_thread.joinable()) e->enc_thread.join();
   e->release();
   delete e;
 }
@@ -612,71 +620,128 @@ int pconv_ee_steps(const pconv_entropy_engine *e) { return e ? e->nsteps : -1; }
 
 // symbols: device float (nimg*npart, ngroup, h, w) quantiser indices (dead
 // columns are ignored).  Streams are kept inside the engine (pconv_ee_stream).
-int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream) {
+// encode in two halves.  begin: the GPU part of every group is queued behind the caller's
+// stream and a host thread is started that, group by group, waits for the tables and runs the
+// arithmetic coders (one thread per frame); begin returns at once, so the caller can go on
+// queueing GPU work (the analysis transform of the next frames) while the CPU codes.  end:
+// joins that thread, makes the caller's stream wait for the group streams and reports.  The
+// symbols tensor must stay alive until end.
+int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *stream) {
   PCONV_REQUIRE(e && symbols, "ee_encode: bad argument");
+  PCONV_REQUIRE(!e->enc_thread.joinable(), "ee_encode: the previous encode has not been ended");
   for (int l = 0; l < kLayers; l++) PCONV_REQUIRE(e->bound[l], "ee_encode: layer %d has no weights", l);
   hipStream_t caller = as_stream(stream);
-  const int cols = e->nlevels + 1;
-  PC_TRY(e->fork(caller));
-  // The bulk kernels fill the GPU on their own, so the groups run one after the
-  // other (not side by side like the decoder's latency-bound steps): the first
-  // group's tables are on the host half-way and its frames are coded on the CPU
-  // while the GPU works on the second group.
+  // The bulk kernels fill the GPU on their own, so the groups run one after the other (not
+  // side by side like the decoder's latency-bound steps) and IN the caller's stream: queued on
+  // streams of their own they are starved by whatever the caller queues next (measured: behind
+  // the analysis transform of the following frames the tables arrived 0.4-0.5 s late).  The
+  // first group's tables are on the host half-way and its frames are coded on the CPU while
+  // the GPU works on the second group and on what the caller queues after this call.
   for (size_t k = 0; k < e->groups.size(); k++) {
     Group &g = e->groups[k];
-    if (k > 0) HIP_TRY(hipStreamWaitEvent(g.stream, e->groups[k - 1].done, 0));
-    PC_TRY(e->encode_tables(g, symbols));
-    HIP_TRY(hipEventRecord(g.done, g.stream));
+    hipStream_t own = g.stream;
+    g.stream = caller;
+    const int rc = e->encode_tables(g, symbols);
+    g.stream = own;
+    PC_TRY(rc);
+    HIP_TRY(hipEventRecord(g.done, caller));
   }
-  // the per-image coder threads report through an atomic and per-image strings; the
-  // thread-local error slot is written by the calling thread after the joins
-  std::atomic<int> status{0};
-  std::vector<std::string> errors(e->nimg);
-  const bool timing = getenv("PCONV_ENGINE_TIMING") != nullptr;
-  const auto t_begin = std::chrono::steady_clock::now();
-  double t_wait = 0, t_coder = 0;
-  for (Group &g : e->groups) {
-    const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    const auto t1 = std::chrono::steady_clock::now();
-    t_wait += std::chrono::duration<double>(t1 - t0).count();
-    for_each_image(g.nimg, [&](int i) {
-      const int img = g.first + i;
-      pconv_coder *c = e->coders[img];
-      int rc = pconv_coder_start_encoder(c);
-      for (int s = 0; s < e->nsteps && rc >= 0; s++) {
-        const size_t len = (size_t)(g.step_row[s + 1] - g.step_row[s]) / g.nimg;
-        if (!len) continue;
-        const size_t r0 = (size_t)g.step_row[s] + (size_t)i * len;
-        rc = pconv_coder_encodes(c, g.tables_h + r0 * cols, e->nlevels, g.labels_h + r0, (int)len);
-      }
-      if (rc >= 0) rc = pconv_coder_end_encoder(c);
-      if (rc < 0) {
-        status.store(rc, std::memory_order_relaxed);
-        errors[img] = std::string("ee_encode: coder of image ") + std::to_string(img) + ": " + pconv_coder_error(c);
+  e->enc_status.store(0);
+  e->enc_errors.assign(e->nimg, std::string());
+  e->enc_begin = std::chrono::steady_clock::now();
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  e->enc_thread = std::thread([e, device] {
+    const int cols = e->nlevels + 1;
+    if (hipSetDevice(device) != hipSuccess) {
+      e->enc_status.store(PCONV_ELAUNCH);
+      e->enc_errors[0] = "ee_encode: hipSetDevice failed in the coder thread";
+      return;
+    }
+    // one host thread per group: each waits for its own tables and codes its frames, so the
+    // groups' coding overlaps (the GPU parts run one after the other in the caller's stream)
+    std::vector<double> waits(e->groups.size(), 0.0), coders(e->groups.size(), 0.0);
+    auto code_group = [&](size_t k) {
+      Group &g = e->groups[k];
+      if (hipSetDevice(device) != hipSuccess) {
+        e->enc_status.store(PCONV_ELAUNCH);
+        e->enc_errors[g.first] = "ee_encode: hipSetDevice failed in a coder thread";
         return;
       }
-      size_t nb = 0;
-      const uint8_t *p = pconv_coder_bytes(c, &nb);
-      e->streams[img].assign(p, p + nb);
-    });
-    t_coder += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-  }
-  if (timing)
+      const auto t0 = std::chrono::steady_clock::now();
+      if (hipEventSynchronize(g.done) != hipSuccess) {  // the group's tables and labels are on the host
+        e->enc_status.store(PCONV_ELAUNCH);
+        e->enc_errors[g.first] = "ee_encode: the encode stream failed";
+        return;
+      }
+      const auto t1 = std::chrono::steady_clock::now();
+      waits[k] = std::chrono::duration<double>(t1 - t0).count();
+      for_each_image(g.nimg, [&](int i) {
+        const int img = g.first + i;
+        pconv_coder *c = e->coders[img];
+        int rc = pconv_coder_start_encoder(c);
+        for (int s = 0; s < e->nsteps && rc >= 0; s++) {
+          const size_t len = (size_t)(g.step_row[s + 1] - g.step_row[s]) / g.nimg;
+          if (!len) continue;
+          const size_t r0 = (size_t)g.step_row[s] + (size_t)i * len;
+          rc = pconv_coder_encodes(c, g.tables_h + r0 * cols, e->nlevels, g.labels_h + r0, (int)len);
+        }
+        if (rc >= 0) rc = pconv_coder_end_encoder(c);
+        if (rc < 0) {
+          // per-image strings: the thread-local error slot belongs to the caller of end
+          e->enc_status.store(rc, std::memory_order_relaxed);
+          e->enc_errors[img] = std::string("ee_encode: coder of image ") + std::to_string(img) + ": " + pconv_coder_error(c);
+          return;
+        }
+        size_t nb = 0;
+        const uint8_t *p = pconv_coder_bytes(c, &nb);
+        e->streams[img].assign(p, p + nb);
+      });
+      coders[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    };
+    {
+      std::vector<std::thread> pool;
+      for (size_t k = 1; k < e->groups.size(); k++) pool.emplace_back(code_group, k);
+      code_group(0);
+      for (std::thread &t : pool) t.join();
+    }
+    double t_wait = 0, t_coder = 0;
+    for (size_t k = 0; k < e->groups.size(); k++) {
+      t_wait = std::max(t_wait, waits[k]);
+      t_coder = std::max(t_coder, coders[k]);
+    }
+    e->enc_wait = t_wait;
+    e->enc_coder = t_coder;
+  });
+  return PCONV_OK;
+}
+
+int pconv_ee_encode_end(pconv_entropy_engine *e, void *stream) {
+  PCONV_REQUIRE(e, "ee_encode: bad argument");
+  PCONV_REQUIRE(e->enc_thread.joinable(), "ee_encode_end: no encode in flight");
+  e->enc_thread.join();
+  if (getenv("PCONV_ENGINE_TIMING"))
     fprintf(stderr, "[pconv engine] encode %d frame(s) in %d group(s): %.1f ms, of which GPU wait %.1f ms, coder %.1f ms\n",
             e->nimg, (int)e->groups.size(),
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3, t_wait * 1e3,
-            t_coder * 1e3);
-  PC_TRY(e->join(caller));
-  if (status.load() < 0) {
-    for (const std::string &m : errors)
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - e->enc_begin).count() * 1e3,
+            e->enc_wait * 1e3, e->enc_coder * 1e3);
+  (void)stream;  // everything was queued in the caller's stream: nothing to join
+  if (e->enc_status.load() < 0) {
+    for (const std::string &m : e->enc_errors)
       if (!m.empty()) {
         pconv_set_error("%s", m.c_str());
         break;
       }
-    return PCONV_EINVAL;
+    return e->enc_status.load() == PCONV_ELAUNCH ? PCONV_ELAUNCH : PCONV_EINVAL;
   }
   return PCONV_OK;
+}
+
+// symbols: device float (nimg*npart, ngroup, h, w) quantiser indices (dead
+// columns are ignored).  Streams are kept inside the engine (pconv_ee_stream).
+int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream) {
+  PC_TRY(pconv_ee_encode_begin(e, symbols, stream));
+  return pconv_ee_encode_end(e, stream);
 }
 
 const uint8_t *pconv_ee_stream(const pconv_entropy_engine *e, int img, size_t *nbytes) {

@@ -233,6 +233,51 @@ __global__ __launch_bounds__(kBlock) void gmm_loss_kernel(
   }
 }
 
+// ProjectsOp.backward (projects_cuda.cu:257-329): the transpose of the viewport sampling, with
+// the same float atomics as the reference; `count` receives the sampling weights
+__global__ __launch_bounds__(kBlock) void project_backward_kernel(const float *__restrict__ gout,
+                                                                  const float *__restrict__ tf,
+                                                                  float *__restrict__ gin, float *__restrict__ count,
+                                                                  int inner, int hs, int ws, int nc, int nearest,
+                                                                  long long total) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int ps = (int)(i % inner);
+    const long long rest = i / inner;
+    const int tn = (int)(rest % nc);
+    const int tb = (int)(rest / nc);
+    const float fx = tf[((size_t)tb * inner + ps) * 2];
+    const float fy = tf[((size_t)tb * inner + ps) * 2 + 1];
+    float *img = gin + (size_t)tn * hs * ws;
+    float *cnt = count + (size_t)tn * hs * ws;
+    const float g = gout[i];
+    if (nearest) {
+      int tw = static_cast<int>(floor(fx + 0.5)) % ws;
+      int th = static_cast<int>(floor(fy + 0.5));
+      th = th >= hs ? hs - 1 : th;
+      atomicAdd(img + (size_t)th * ws + tw, g);
+      atomicAdd(cnt + (size_t)th * ws + tw, 1.f);
+    } else {
+      const int tw = static_cast<int>(floorf(fx));
+      const int th = static_cast<int>(floorf(fy));
+      const int pw = (tw + 1) % ws;
+      const int ph = th + 1 >= hs ? hs - 1 : th + 1;
+      const float tx = fx - tw;
+      const float ty = fy - th;
+      const float ntx = 1. - tx;
+      const float nty = 1. - ty;
+      atomicAdd(img + (size_t)th * ws + tw, ntx * nty * g);
+      atomicAdd(cnt + (size_t)th * ws + tw, ntx * nty);
+      atomicAdd(img + (size_t)th * ws + pw, tx * nty * g);
+      atomicAdd(cnt + (size_t)th * ws + pw, tx * nty);
+      atomicAdd(img + (size_t)ph * ws + tw, ntx * ty * g);
+      atomicAdd(cnt + (size_t)ph * ws + tw, ntx * ty);
+      atomicAdd(img + (size_t)ph * ws + pw, tx * ty * g);
+      atomicAdd(cnt + (size_t)ph * ws + pw, tx * ty);
+    }
+  }
+}
+
 // PseudoQuantOp.backward (pseudo_quant_cuda.cu:197-311), one pass over the activation:
 //   g_in = g_val + alpha * g_idx / beta   (straight-through for the value, the index output's
 //          gradient scaled by the width of the level interval the input sits in), zero in the
@@ -387,5 +432,24 @@ extern "C" int pconv_quant_backward(const float *x, const float *val, const floa
   hipLaunchKernelGGL(quant_weight_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), bins,
                      level_tab, g_weight, c, levels);
   PCONV_LAUNCH_CHECK("quant_backward");
+  return PCONV_OK;
+}
+
+// ProjectsOp.backward: gout (n*nview, c, h_out, w_out) -> gin, count (n, c, height, width)
+extern "C" int pconv_project_backward(const float *gout, const float *tf, float *gin, float *count, int n, int c,
+                                      int height, int width, int nview, int h_out, int w_out, int nearest,
+                                      void *stream) {
+  PCONV_REQUIRE(gout && tf && gin && count, "project_backward: null pointer");
+  PCONV_REQUIRE(n > 0 && c > 0 && nview > 0, "project_backward: bad shape");
+  const size_t bytes = (size_t)n * c * height * width * sizeof(float);
+  if (hipMemsetAsync(gin, 0, bytes, as_stream(stream)) != hipSuccess ||
+      hipMemsetAsync(count, 0, bytes, as_stream(stream)) != hipSuccess) {
+    pconv_set_error("project_backward: memset failed");
+    return PCONV_ELAUNCH;
+  }
+  const long long total = (long long)n * c * nview * h_out * w_out;
+  hipLaunchKernelGGL(project_backward_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), gout, tf,
+                     gin, count, h_out * w_out, height, width, n * c, nearest, total);
+  PCONV_LAUNCH_CHECK("project_backward");
   return PCONV_OK;
 }

@@ -8,6 +8,8 @@ engine, several frames in lock-step.  The streams are byte-identical to the ones
 the per-op PseudoEncoder path writes, so either side can decode the other's files.
 """
 import ctypes
+import os
+import threading
 
 import numpy as np
 import torch
@@ -74,20 +76,44 @@ class EntropyEngine(object):
     def symbols_per_image(self):
         return int(self.lib.pconv_ee_symbols_per_image(self.handle))
 
-    def encode(self, symbols):
-        """symbols (nimg*npart, ngroup, h, w) float indices, dead columns zero -> [bytes] per frame"""
+    def _check_symbols(self, symbols):
         expect = (self.nimg * self.npart, self.ngroup, self.h, self.w)
         if tuple(symbols.shape) != expect or not symbols.is_cuda or not symbols.is_contiguous():
             raise PconvError("EntropyEngine.encode: expected contiguous GPU tensor %s, got %s" % (expect, tuple(symbols.shape)))
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            call("pconv_ee_encode", self.handle, symbols.data_ptr(), stream)
+
+    def _streams(self):
         out = []
         for i in range(self.nimg):
             n = ctypes.c_size_t(0)
             p = self.lib.pconv_ee_stream(self.handle, i, ctypes.byref(n))
             out.append(ctypes.string_at(p, n.value))
         return out
+
+    def encode(self, symbols):
+        """symbols (nimg*npart, ngroup, h, w) float indices, dead columns zero -> [bytes] per frame"""
+        self._check_symbols(symbols)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            call("pconv_ee_encode", self.handle, symbols.data_ptr(), stream)
+        return self._streams()
+
+    def encode_begin(self, symbols):
+        """first half of encode: queues the GPU part and starts the host coder thread, returns at
+        once; the caller may queue other GPU work before encode_end()"""
+        self._check_symbols(symbols)
+        self._pending = symbols  # kept alive until encode_end
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            call("pconv_ee_encode_begin", self.handle, symbols.data_ptr(), stream)
+
+    def encode_end(self):
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            try:
+                call("pconv_ee_encode_end", self.handle, stream)
+            finally:
+                self._pending = None
+        return self._streams()
 
     def decode(self, streams):
         if len(streams) != self.nimg:
@@ -114,8 +140,8 @@ class CodecEngine(object):
         self.dec = decoder if decoder is not None else PC.PseudoDecoder(valid_dim, device_id)
         self._engines = {}
 
-    def _engine(self, which, h, w, nimg):
-        key = (which, h, w, nimg)
+    def _engine(self, which, h, w, nimg, slot=0):
+        key = (which, h, w, nimg, slot)
         ent = self.enc.ent if which == "enc" else self.dec.ent
         if key not in self._engines:
             self._engines[key] = EntropyEngine(ent, h, w, nimg, self.device)
@@ -134,19 +160,69 @@ class CodecEngine(object):
         per_frame = [self.enc.ent.fill(self.enc.symbols(frames[i:i + 1])).clone() for i in range(frames.shape[0])]
         return per_frame[0] if len(per_frame) == 1 else torch.cat(per_frame, 0)
 
+    # frames entropy-coded per pipeline stage of encode(): the stage's tables are arithmetic-coded
+    # on the CPU while the GPU runs the analysis transform of the following frames
+    ENCODE_CHUNK = 2
+
     @torch.no_grad()
     def encode(self, frames):
-        """(n, 3, H, W) frames on the GPU -> n byte strings; the n frames go through
-        the entropy wavefront in lock-step"""
-        sym = self.symbols(frames)
-        eng = self._engine("enc", sym.shape[2], sym.shape[3], frames.shape[0])
-        return eng.encode(sym.contiguous())
+        """(n, 3, H, W) frames on the GPU -> n byte strings.  The frames of a chunk go through the
+        entropy wavefront in lock-step; the chunks are pipelined: chunk k's CDF tables are coded by
+        host threads while the GPU computes the symbols of chunk k+1 (each chunk has its own
+        engine: the coder reads the engine's pinned buffers until encode_end)."""
+        n = frames.shape[0]
+        chunk = self.ENCODE_CHUNK if n > self.ENCODE_CHUNK else n
+        pending, out = [], []
+        for k, lo in enumerate(range(0, n, chunk)):
+            sym = self.symbols(frames[lo:lo + chunk]).contiguous()
+            eng = self._engine("enc", sym.shape[2], sym.shape[3], sym.shape[0] // self.enc.ent.npart, slot=k)
+            eng.encode_begin(sym)
+            pending.append(eng)
+        for eng in pending:
+            out += eng.encode_end()
+        return out
+
+    # frames per pipeline stage of decode(); 0 = decode all frames of a call together, then run the
+    # synthesis transforms (PCONV_DECODE_CHUNK overrides)
+    DECODE_CHUNK = int(os.environ.get("PCONV_DECODE_CHUNK", "0"))
 
     @torch.no_grad()
     def decode(self, streams, height, width):
+        """n byte strings -> (n, 3, H, W).  With DECODE_CHUNK = c > 0 and more than c frames the call
+        is pipelined: while the synthesis transform of chunk k runs, the entropy decoder of chunk k+1
+        (a latency chain that leaves most of the GPU idle) runs beside it on a second stream, driven
+        by a host thread; two engines alternate."""
         h, w = PC.latent_shape(height, width, self.dec.npart)
         n = len(streams)
-        sym = self._engine("dec", 2 * h, 2 * w, n).decode(streams)
         tiles = self.dec.npart
-        out = [self.dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(n)]
-        return out[0] if n == 1 else torch.cat(out, 0)
+        chunk = self.DECODE_CHUNK
+        if chunk <= 0 or n <= chunk:
+            sym = self._engine("dec", 2 * h, 2 * w, n).decode(streams)
+            out = [self.dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(n)]
+            return out[0] if n == 1 else torch.cat(out, 0)
+        chunks = [streams[i:i + chunk] for i in range(0, n, chunk)]
+        side = torch.cuda.Stream(device=self.device)
+        box = {}
+
+        def run(k):
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(side):
+                    box[k] = self._engine("dec", 2 * h, 2 * w, len(chunks[k]), slot=k % 2).decode(chunks[k])
+            except BaseException as exc:  # re-raised by the caller's thread
+                box[k] = exc
+
+        run(0)
+        out = []
+        for k in range(len(chunks)):
+            sym = box.pop(k)
+            if isinstance(sym, BaseException):
+                raise sym
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            worker = None
+            if k + 1 < len(chunks):
+                worker = threading.Thread(target=run, args=(k + 1,))
+                worker.start()
+            out += [self.dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(len(chunks[k]))]
+            if worker is not None:
+                worker.join()
+        return torch.cat(out, 0)

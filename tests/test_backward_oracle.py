@@ -120,3 +120,14 @@ def test_quantiser_autograd_bridge_on_the_oracle(oracle_backend):
         assert x.grad[t::16, :, :, v:].abs().sum().item() == 0
     assert q.weight.grad is not None and q.weight.grad.abs().sum().item() > 0
     assert int(-q.count.grad.sum().item()) == 8 * 2 * 836                  # one count per valid element
+
+
+@pytest.mark.parametrize("near", [False, True])
+def test_projects_backward_is_the_transpose(near):
+    th = [-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0]
+    ph = [0, 0, 0, 0, 0.25, 0.25, 0.25, 0.25, -0.25, -0.25, -0.25, -0.25, 0.5, -0.5]
+    op = O.ProjectsOp(19, 28, th, ph, 0.5, near)
+    x = torch.randn(2, 3, 64, 128, generator=torch.Generator().manual_seed(21))
+    _adjoint(lambda t: op.forward(t)[0], lambda g: op.backward(g)[0], x, (28, 3, 19, 28))
+    cnt = op.backward(torch.ones(28, 3, 19, 28))[1]
+    assert abs(cnt.sum().item() - 28 * 3 * 19 * 28) < 1.0     # the bilinear weights of a sample sum to 1

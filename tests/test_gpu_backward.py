@@ -161,3 +161,17 @@ def test_quant_backward(ntop):
         for t in range(16):
             v = int(widths[t])
             assert torch.equal(gg[0][t::16, :, :, :v].cpu(), grads[0][t::16, :, :, :v])
+
+
+@pytest.mark.parametrize("near", [False, True])
+def test_projects_backward(near):
+    th = [-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0]
+    ph = [0, 0, 0, 0, 0.25, 0.25, 0.25, 0.25, -0.25, -0.25, -0.25, -0.25, 0.5, -0.5]
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(1, 3, 256, 512, generator=g)
+    gop, cop = P().ProjectsOp(171, 256, th, ph, 0.5, near, 0, False), O.ProjectsOp(171, 256, th, ph, 0.5, near)
+    yg, yc = gop.forward(x.to(DEV))[0], cop.forward(x)[0]
+    grad = torch.randn(yc.shape, generator=g)
+    (gg, cg), (gc, cc) = gop.backward(grad.to(DEV)), cop.backward(grad)
+    close(gg, gc, 1e-4)      # float atomics: the order of the sums is not defined
+    close(cg, cc, 1e-4)

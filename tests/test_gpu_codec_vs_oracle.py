@@ -297,3 +297,30 @@ def test_viewport_metrics_at_metric_size(hip_backend):
         backend.reset()
     assert 25 < psnr_g < 45 and 0.5 < ssim_g < 1
     assert abs(psnr_g - psnr_c) < 1e-3 and abs(ssim_g - ssim_c) < 1e-4
+
+
+@pytest.mark.timeout(1500)
+def test_analysis_transform_config3_vs_oracle(hip_backend):
+    """BASELINE config #3: SphereSlice + EncoderV2 (4 pseudo-conv stages + GDN) on 1x3x1024x2048,
+    seeded default-init weights: the HIP path (fp32-MFMA tile convolutions, fused epilogues, ring
+    pads) against the oracle-backend run of the same graph (torch CPU conv), <= 1e-4"""
+    from pseudocylindrical_convolution_amd.PCONV_operator import backend
+    from oracle import coder_cpu
+    H, W = 1024, 2048
+    x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(2))
+    enc, _ = _codec()
+    with torch.no_grad():
+        yg = enc.encoder(enc.slice(x.cuda())).cpu()
+    backend.use(O, coder_cpu)
+    try:
+        cenc, _ = _codec()
+        with torch.no_grad():
+            yc = cenc.encoder(cenc.slice(x))
+    finally:
+        backend.reset()
+    assert tuple(yg.shape) == (16, 192, 4, 128)
+    err = (yg - yc).abs().max().item()
+    assert err < 1e-4, "analysis transform differs from the oracle by %g" % err
+    widths = O.widths_v3(W16, 16, 64, 128)
+    for t in range(16):
+        assert yg[t, :, :, int(widths[t]):].abs().max().item() == 0 if widths[t] < 128 else True

@@ -144,3 +144,22 @@ def test_queued_chain_equals_host_driven_chain(hip_backend, monkeypatch):
         assert torch.equal(queued, sym[:16 * n])
         again = e.decode(streams[:n])   # flags and counters are back in their initial state
         assert torch.equal(again, queued)
+
+
+def test_pipelined_decode_equals_plain_decode(hip_backend, monkeypatch):
+    """CodecEngine.decode with DECODE_CHUNK: the entropy decoder of chunk k+1 runs beside the
+    synthesis of chunk k (second stream, host thread, two engines) -- same images"""
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = _codec()
+    eng = CodecEngine(56, 0, enc, dec)
+    x = _frames(5, 256, 512, seed=17)
+    streams = eng.encode(x)
+    plain = eng.decode(streams, 256, 512)
+    monkeypatch.setattr(CodecEngine, "DECODE_CHUNK", 2)
+    piped = eng.decode(streams, 256, 512)
+    assert torch.equal(plain, piped)
+    # chunked encode == one lock-step encode of all frames == frames one by one
+    monkeypatch.setattr(CodecEngine, "ENCODE_CHUNK", 8)
+    assert eng.encode(x) == streams
+    monkeypatch.setattr(CodecEngine, "ENCODE_CHUNK", 1)
+    assert eng.encode(x) == streams
