@@ -203,6 +203,19 @@ int pconv_pseudo_pad_backward(const float *gout, float *gin, const int32_t *widt
                               const int32_t *rev_start, const int32_t *rev_dst, const float *rev_wgt,
                               int tn, int c, int h, int w, int pad, int npart, void *stream);
 
+/* PseudoEntropyPadOp.forward / backward (pseudo_entropy_pad_cuda.cu:39-241): the causal pad of the
+ * training-time entropy net -- halo rows through pconv_host_causal_table, right wrap only, no pole
+ * mirror.  in (tn, c, h, w) <-> out (tn, c, h+2p, w+2p). */
+int pconv_entropy_pad(const float *in, float *out, const int32_t *widths, const int32_t *col,
+                      const float *wgt, int tn, int c, int h, int w, int pad, int npart, void *stream);
+int pconv_host_entropy_pad_table(const int32_t *widths, int npart, int height, int width, int pad,
+                                 int version, int32_t *col, float *wgt);
+int pconv_host_causal_reverse(const int32_t *widths, int npart, int height, int width, int pad,
+                              int version, int32_t *rev_start, int32_t *rev_dst, float *rev_wgt);
+int pconv_entropy_pad_backward(const float *gout, float *gin, const int32_t *widths,
+                               const int32_t *rev_start, const int32_t *rev_dst, const float *rev_wgt,
+                               int tn, int c, int h, int w, int pad, int npart, void *stream);
+
 /* ProjectsOp.backward (projects_cuda.cu:257-329): gout (n*nview, c, h_out, w_out) -> gin and count
  * (n, c, height, width); count = the sampling weights each source pixel received. */
 int pconv_project_backward(const float *gout, const float *tf, float *gin, float *count, int n, int c,

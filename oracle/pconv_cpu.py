@@ -152,6 +152,19 @@ class PseudoEntropyContextOp(_Context):
         super().__init__(npart, rt, weight, device, timeit)
         self.context_version_ = context_version
 
+    def produce_param(self, channel, height, width, pad):
+        key = ("param", width, channel, pad, height)
+        if key not in self.cache:
+            hidx = self.hindex(height, width)
+            n = self.npart_ * 2 * pad * width
+            dst, src = np.zeros(n, np.int64), np.zeros(n, np.int64)
+            pcol, pt = np.zeros(n, np.int32), np.zeros(n, np.float32)
+            h2 = np.zeros(self.npart_ * 2 * pad, np.int32)
+            lib().orc_pseudo_entropy_context(_p(hidx), _p(h2), _p(dst), _p(src), _p(pcol), _p(pt), I(channel),
+                                             I(height), I(width), I(self.npart_), I(pad), I(self.context_version_))
+            self.cache[key] = (hidx, h2, dst, src, pcol, pt)
+        return self.cache[key]
+
 
 class EntropyContextOp(_Context):
 
@@ -260,6 +273,9 @@ class MaskConstrainOp(_Base):
     def forward(self, w):
         nout, cin, k, _ = w.shape
         lib().orc_mask_constrain(_p(w), I(nout), I(cin), I(k), I(self.ngroup_), I(self.constrain_))
+
+    def backward(self, grad):
+        self.forward(grad)
 
 
 class SphereSliceOp(_Base):
@@ -375,14 +391,39 @@ class PseudoFillOp(_Base):
                               I(self.trim_), F(self.fvalue_))
         return [x]
 
+    def backward(self, grad):
+        # pseudo_fill_cuda.cu:63-77: the same kernel on the gradient, filling zeros
+        num, c, h, w = grad.shape
+        hidx = self.ctx_.hindex(h, w)
+        lib().orc_pseudo_fill(_p(grad), _p(hidx), I(num), I(c), I(h), I(w), I(self.npart_), I(self.pad_),
+                              I(self.trim_), F(0.0))
+        return [grad]
+
 
 class PseudoEntropyPadOp(_Base):
 
     def __init__(self, pad, npart, addr, device=0, timeit=False):
         super().__init__(device, timeit)
+        self.pad_, self.npart_, self.ctx_ = pad, npart, _ctx(addr)
 
     def forward(self, x):
-        raise NotImplementedError("training-only op, outside the codec hot path")
+        num, c, h, w = x.shape
+        p = self.pad_
+        hidx, h2, dst, src, pcol, pt = self.ctx_.produce_param(c, h, w, p)
+        out = self._top(0, (num, c, h + 2 * p, w + 2 * p))
+        lib().orc_entropy_pad(_p(x), _p(out), _p(hidx), _p(h2), _p(dst), _p(src), _p(pcol), _p(pt), I(num), I(c),
+                              I(h), I(w), I(self.npart_), I(p))
+        return [out]
+
+    def backward(self, grad):
+        num, c, hp, wp = grad.shape
+        p = self.pad_
+        h, w = hp - 2 * p, wp - 2 * p
+        hidx, h2, dst, src, pcol, pt = self.ctx_.produce_param(c, h, w, p)
+        gin = self._top(1, (num, c, h, w))
+        lib().orc_entropy_pad_backward(_p(grad.contiguous()), _p(gin), _p(hidx), _p(h2), _p(dst), _p(src), _p(pcol),
+                                       _p(pt), I(num), I(c), I(h), I(w), I(self.npart_), I(p))
+        return [gin]
 
 
 class PseudoQuantOp(_Base):

@@ -1319,3 +1319,183 @@ void orc_projects_backward(float *input, float *count, const float *tf, const fl
     }
   }
 }
+
+/* ---- pseudo_entropy_context_cuda.cu:51-170: the table of the training-time causal pad ---------
+ * per index (tg, tl, tp, tw): dstoff / srcoff = param[0] / param[1] (source in the UNPADDED input),
+ * pcol = param[2] (-1 = no first tap), pt = param[3]; hindex2 = neighbour tile or -1 at the poles.
+ * version 0 = kernel_v0 (:51-108), version 1 = kernel_v1 (:110-170). */
+void orc_pseudo_entropy_context(const int *hindex, int *hindex2, i64 *dstoff, i64 *srcoff, int *pcol, float *pt,
+                                int channel, int height, int width, int npart, int pad, int version) {
+  const int nthreads = npart * width * pad * 2;
+  for (int i = 0; i < npart * 2 * pad; i++) hindex2[i] = 0;
+  for (int index = 0; index < nthreads; index++) {
+    int tw = index % width;
+    int tp = (index / width) % pad;
+    int tl = (index / width) / pad % 2;
+    int tg = index / width / pad / 2;
+    dstoff[index] = 0;
+    srcoff[index] = 0;
+    pcol[index] = 0;
+    pt[index] = 0;
+    if (tw >= hindex[tg]) continue;
+    int ph, pg = 0;
+    float pw = 0;
+    int bound = 0;
+    if (tl == 0) {
+      ph = tg * height - pad + tp;
+      if (ph < 0) bound = 1;
+    } else {
+      ph = (tg + 1) * height + tp;
+      if (ph >= height * npart) bound = 1;
+    }
+    if (!bound) {
+      pg = ph / height;
+      pw = (tw + 0.5) / hindex[tg] * hindex[pg] - 0.5 + 1e-9;
+    }
+    i64 d = (tl == 0) ? (i64)tg * channel * (height + pad * 2) + tp
+                      : (i64)tg * channel * (height + pad * 2) + pad + height + tp;
+    dstoff[index] = d * (width + pad * 2);
+    if (bound) {
+      if (tw == 0) hindex2[(tg * 2 + tl) * pad + tp] = -1;
+      continue;
+    }
+    srcoff[index] = ((i64)pg * channel * height + ph % height) * width;
+    int pidx = pw < 0 ? -1 : (int)pw;
+    if (version == 0) {
+      pcol[index] = pidx;
+      pt[index] = pidx + 1 - pw;
+      float qwa = (pidx + 1 + 0.5) / hindex[pg] * width - 0.5;
+      float qwb = (tw + 0.5) / hindex[tg] * width - 0.5;
+      int qidx = (int)qwb;
+      if (qwa >= qidx + 0.999) {
+        pt[index] = 1.;
+      } else if (pidx == -1) {
+        pt[index] = 0.;
+      }
+    } else {
+      if (pidx > tw) {
+        pcol[index] = -1;
+        pt[index] = 1.;
+      } else if (pidx + 1 > tw) {
+        pcol[index] = pidx;
+        pt[index] = 1.;
+      } else {
+        pcol[index] = pidx;
+        pt[index] = pidx + 1 - pw;
+        if (pidx == -1) pt[index] = 0.;
+      }
+    }
+    if (tw == 0) hindex2[(tg * 2 + tl) * pad + tp] = pg;
+  }
+}
+
+/* ---- pseudo_entropy_pad_cuda.cu:39-100 (three passes, as launched at :113-126) ---------------- */
+void orc_entropy_pad(const float *input, float *output, const int *hindex, const int *hindex2, const i64 *dstoff,
+                     const i64 *srcoff, const int *pcol, const float *pt, int num, int channel, int height,
+                     int width, int npart, int pad) {
+  const int h_out = height + 2 * pad, w_out = width + 2 * pad;
+  i64 nthreads = (i64)num * channel * h_out * w_out;
+  for (i64 index = 0; index < nthreads; index++) { /* copy_forward_kernel */
+    int pw = index % w_out;
+    int ph = (index / w_out) % h_out;
+    i64 ps = index / w_out / h_out;
+    int pg = (ps / channel) % npart;
+    if (pw < pad || pw >= hindex[pg] + pad || ph < pad || ph >= height + pad) {
+      output[index] = 0;
+      continue;
+    }
+    output[index] = input[(ps * height + ph - pad) * width + pw - pad];
+  }
+  const int inner_shape = 2 * pad * width;
+  const i64 astride = (i64)h_out * w_out, astride_out = astride * channel * npart;
+  const i64 bstride = (i64)height * width, bstride_out = bstride * channel * npart;
+  nthreads = (i64)num * channel * width * pad * 2;
+  for (i64 index = 0; index < nthreads; index++) { /* forward_kernel */
+    int pw = index % width;
+    int ps = index % inner_shape;
+    int pc = (index / inner_shape) % channel;
+    int pn = index / inner_shape / channel;
+    int tn = pn / npart;
+    int tg = pn % npart;
+    if (pw >= hindex[tg]) continue;
+    int base = tg * inner_shape + ps;
+    int qg = hindex2[base / width];
+    i64 pbase = dstoff[base] + tn * astride_out + pc * astride;
+    if (qg == -1) {
+      output[pbase + pw + pad] = 0;
+      continue;
+    }
+    i64 qbase = srcoff[base] + tn * bstride_out + pc * bstride;
+    int qw = pcol[base];
+    float qdata = (qw == -1) ? 0 : input[qbase + qw];
+    float t = pt[base];
+    int qww = (qw + 1) % hindex[qg];
+    output[pbase + pw + pad] = qdata * t + input[qbase + qww] * (1 - t);
+  }
+  const int pad2 = pad * 2;
+  nthreads = (i64)num * channel * h_out * pad * 2;
+  for (i64 index = 0; index < nthreads; index++) { /* circle_forward_kernel */
+    int pw = index % pad2;
+    int pn = index / pad2 / h_out / channel;
+    int pg = pn % npart;
+    int pwa = pw % pad;
+    int pwb = pw / pad;
+    int wl = hindex[pg];
+    int qw = pwb * (wl + pad) + pwa;
+    i64 base = index / pad2 * w_out;
+    if (pwb < 1)
+      output[base + qw] = 0;
+    else
+      output[base + qw] = output[base + (qw - pad + wl) % wl + pad];
+  }
+}
+
+/* ---- pseudo_entropy_pad_cuda.cu:135-241 with the inverse lists of pseudo_entropy_context_cuda.cu
+ * :171-209, applied as the scatter they stand for (a tap enters a list only if pcol >= 0 and t > 0;
+ * the second tap only if t < 1).  top_diff is copied first: the reference folds in place. */
+void orc_entropy_pad_backward(const float *top_diff, float *bottom_diff, const int *hindex, const int *hindex2,
+                              const i64 *dstoff, const i64 *srcoff, const int *pcol, const float *pt, int num,
+                              int channel, int height, int width, int npart, int pad) {
+  const int h_out = height + 2 * pad, w_out = width + 2 * pad;
+  const i64 nout = (i64)num * channel * h_out * w_out;
+  float *out = (float *)malloc(sizeof(float) * (size_t)nout);
+  for (i64 i = 0; i < nout; i++) out[i] = top_diff[i];
+  const i64 nrows = (i64)num * channel * h_out;
+  for (i64 index = 0; index < nrows; index++) { /* circle_backward(_lfour)_kernel: right halo only */
+    int pn = index / h_out / channel;
+    int pg = pn % npart;
+    for (int pwa = 0; pwa < pad; pwa++) {
+      int wl = hindex[pg];
+      int qw = wl + pad + pwa;
+      i64 base = index * w_out;
+      out[base + (qw - pad) % wl + pad] += out[base + qw];
+      out[base + qw] = 0.f;
+    }
+  }
+  const i64 nin = (i64)num * channel * height * width;
+  for (i64 index = 0; index < nin; index++) { /* backward_kernel: the interior */
+    int pw = index % width;
+    i64 ps = index / width / height;
+    int ph = (index / width) % height;
+    int pg = (ps / channel) % npart;
+    bottom_diff[index] = pw < hindex[pg] ? out[(ps * h_out + ph + pad) * w_out + pw + pad] : 0.f;
+  }
+  const i64 astride = (i64)h_out * w_out, astride_out = (i64)npart * channel * astride;
+  const i64 bstride = (i64)height * width, bstride_out = (i64)npart * channel * bstride;
+  const int nentries = npart * 2 * pad * width;
+  for (int tn = 0; tn < num / npart; tn++)
+    for (int pc = 0; pc < channel; pc++)
+      for (int e = 0; e < nentries; e++) {
+        int tw = e % width;
+        int tg = e / width / pad / 2;
+        if (tw >= hindex[tg]) continue;
+        int qg = hindex2[e / width];
+        if (qg < 0) continue;
+        float g = out[dstoff[e] + tn * astride_out + pc * astride + tw + pad];
+        i64 q = srcoff[e] + tn * bstride_out + pc * bstride;
+        float t = pt[e];
+        if (pcol[e] >= 0 && t > 0) bottom_diff[q + pcol[e]] += g * t;
+        if (t < 1) bottom_diff[q + (pcol[e] + 1) % hindex[qg]] += g * (1 - t);
+      }
+  free(out);
+}

@@ -196,13 +196,41 @@ class PseudoContextOp(_TileContext):
 
 
 class PseudoEntropyContextOp(_TileContext):
-    """PCONV.PseudoEntropyContextOp (main.cpp:109-113).  Only the geometry used by
-    PseudoFill (context_version 1) is provided; the whole-tensor causal pad of
-    the training-time EntropyNet is outside the codec hot path."""
+    """PCONV.PseudoEntropyContextOp(npart, rt, context_version, weight, device, timeit)
+    (main.cpp:109-113, pseudo_entropy_context_cuda.cu:51-240): tile widths for PseudoFill and
+    the causal halo table (+ its reverse) of the training-time PseudoEntropyPad."""
 
     def __init__(self, npart, rt, context_version, weight, device=0, timeit=False):
         super().__init__(npart, rt, weight, device, timeit)
         self.context_version_ = int(context_version)
+        if self.context_version_ not in (0, 1):
+            raise ValueError("PseudoEntropyContextOp: undefined context version %r" % (context_version,))
+
+    def causal_tables(self, height, width, pad, like):
+        """(col, wgt): per (tile, side, halo row, column) first source column (-2 none, -1 second
+        tap only) and its weight"""
+        key = ("cpad", int(height), int(width), int(pad), like.device)
+        if key not in self._cache:
+            wh = self.widths_host(height, width)
+            n = self.npart_ * 2 * pad * width
+            col, wgt = np.zeros(n, np.int32), np.zeros(n, np.float32)
+            call("pconv_host_entropy_pad_table", _np_ptr(wh), self.npart_, height, width, pad,
+                 self.context_version_, _np_ptr(col), _np_ptr(wgt))
+            self._cache[key] = tuple(self._upload(a, like) for a in (col, wgt))
+        return self._cache[key]
+
+    def causal_reverse_tables(self, height, width, pad, like):
+        """reverse CSR of causal_tables for PseudoEntropyPadOp.backward (pconv_host_causal_reverse)"""
+        key = ("cpadrev", int(height), int(width), int(pad), like.device)
+        if key not in self._cache:
+            wh = self.widths_host(height, width)
+            start = np.zeros(self.npart_ * height * width + 1, np.int32)
+            cap = 4 * self.npart_ * pad * width
+            dst, wgt = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+            call("pconv_host_causal_reverse", _np_ptr(wh), self.npart_, height, width, pad,
+                 self.context_version_, _np_ptr(start), _np_ptr(dst), _np_ptr(wgt))
+            self._cache[key] = tuple(self._upload(a, like) for a in (start, dst, wgt))
+        return self._cache[key]
 
 
 class EntropyContextOp(_TileContext):
@@ -512,20 +540,38 @@ class PseudoFillOp(_Op):
 
 
 class PseudoEntropyPadOp(_Op):
-    """PCONV.PseudoEntropyPadOp (main.cpp:115-119).  Training-only op of the
-    reference's EntropyNet; declared so the module surface is complete."""
+    """PCONV.PseudoEntropyPadOp(pad, npart, addr, device, timeit) (main.cpp:115-119,
+    pseudo_entropy_pad_cuda.cu:39-241): causal pad of the training-time EntropyNet."""
 
     def __init__(self, pad, npart, addr, device=0, timeit=False):
         super().__init__(device, timeit)
         self.pad_, self.npart_ = int(pad), int(npart)
         self.ctx_ = _lookup(addr)
+        if not isinstance(self.ctx_, PseudoEntropyContextOp):
+            raise TypeError("PseudoEntropyPadOp needs the address of a PseudoEntropyContextOp")
 
     def forward(self, x):
-        raise NotImplementedError(
-            "PseudoEntropyPadOp.forward: whole-tensor causal pad of the training-time EntropyNet "
-            "is outside the codec hot path (SURVEY 2.1, 8f-4)")
+        _require_gpu(x, "PseudoEntropyPadOp.forward")
+        tn, c, h, w = x.shape
+        p = self.pad_
+        wd = self.ctx_.widths(h, w, x)
+        col, wgt = self.ctx_.causal_tables(h, w, p, x)
+        out = self._out(0, (tn, c, h + 2 * p, w + 2 * p), x)
+        call("pconv_entropy_pad", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(wgt), tn, c, h, w, p, self.npart_,
+             _stream(x.device))
+        return [out]
 
-    backward = forward
+    def backward(self, grad):
+        _require_gpu(grad, "PseudoEntropyPadOp.backward")
+        tn, c, hp, wp = grad.shape
+        p = self.pad_
+        h, w = hp - 2 * p, wp - 2 * p
+        wd = self.ctx_.widths(h, w, grad)
+        rs, rd, rw = self.ctx_.causal_reverse_tables(h, w, p, grad)
+        out = self._out(1, (tn, c, h, w), grad)
+        call("pconv_entropy_pad_backward", _ptr(grad), _ptr(out), _ptr(wd), _ptr(rs), _ptr(rd), _ptr(rw), tn, c, h,
+             w, p, self.npart_, _stream(grad.device))
+        return [out]
 
 
 class PseudoQuantOp(_Op):

@@ -84,7 +84,8 @@ class _NativeCall(torch.autograd.Function):
         if not g.is_contiguous():
             g = g.contiguous()
         res = ctx.op.backward(g)
-        return (None, None, None, None, res[0]) + (None,) * (ctx.n_in - 1)
+        # one gradient per tensor argument where the op has one (EntropyGmm: weight, delta, mean, label)
+        return (None, None, None, None) + tuple(res[i] if i < len(res) else None for i in range(ctx.n_in))
 
 
 def native_call(module, method, tensors, n_out=1, grad_mode='first'):

@@ -48,6 +48,10 @@ _HIP_SIGNATURES = {
     "pconv_pseudo_pad_backward": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_quant_backward": [P, P, P, P, P, P, P, P, P, P, F, I, I, I, I, I, I, P],
     "pconv_project_backward": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "pconv_entropy_pad": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "pconv_host_entropy_pad_table": [P, I, I, I, I, I, P, P],
+    "pconv_host_causal_reverse": [P, I, I, I, I, I, P, P, P],
+    "pconv_entropy_pad_backward": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_gmm_loss": [P, P, P, P, P, P, P, P, P, I, I, P],
     "pconv_conv_packed_size": [I, I, I, P, P],
     "pconv_conv_pack_weight": [P, P, I, I, I, P],

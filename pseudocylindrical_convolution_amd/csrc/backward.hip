@@ -120,14 +120,16 @@ int rows_per_block(int tile_rows, int width) {
 // gradient that reaches padded element (row pointer, unpadded column col) of a tile whose
 // valid width is wl, after the circular wrap columns have been folded back onto the interior
 // columns they were copied from (transpose of pseudo_pad.cu:82-96)
+template <bool CAUSAL>
 __device__ __forceinline__ float folded(const float *rowp, int col, int wl, int pad) {
   float v = rowp[col + pad];
-  if (col < pad) v += rowp[wl + pad + col];          // right halo column that copied this one
-  if (col >= wl - pad) v += rowp[col - (wl - pad)];  // left halo column that copied this one
-  return v;
+  if (col < pad) v += rowp[wl + pad + col];                     // right halo column that copied this one
+  if (!CAUSAL && col >= wl - pad) v += rowp[col - (wl - pad)];  // left halo column that copied this one
+  return v;  // (the causal pad of the entropy model leaves the left halo columns zero)
 }
 
 // one thread per input element (tn, c, row, col)
+template <bool CAUSAL>
 __global__ __launch_bounds__(kBlock) void pad_backward_kernel(
     const float *__restrict__ gout, float *__restrict__ gin, const int32_t *__restrict__ widths,
     const int32_t *__restrict__ rev_start, const int32_t *__restrict__ rev_dst, const float *__restrict__ rev_wgt,
@@ -143,17 +145,80 @@ __global__ __launch_bounds__(kBlock) void pad_backward_kernel(
     const int wl = widths[t];
     float v = 0.f;
     if (col < wl) {
-      v = folded(gout + ((size_t)plane * hp + row + pad) * wp, col, wl, pad);
+      v = folded<CAUSAL>(gout + ((size_t)plane * hp + row + pad) * wp, col, wl, pad);
       const int key = (t * h + row) * w + col;
       for (int k = rev_start[key]; k < rev_start[key + 1]; k++) {
         const int d = rev_dst[k];
         const int td = d >> 24, off = d & 0xffffff;  // destination tile, padded row*wp + unpadded column
         const int prow = off / w, dcol = off - prow * w;
         const float *rowp = gout + (((size_t)(tn - t + td) * c + pc) * hp + prow) * wp;
-        v += rev_wgt[k] * folded(rowp, dcol, widths[td], pad);
+        v += rev_wgt[k] * folded<CAUSAL>(rowp, dcol, widths[td], pad);
       }
     }
     gin[i] = v;
+  }
+}
+
+// PseudoEntropyPad.forward (pseudo_entropy_pad_cuda.cu:39-134, three launches there): the causal
+// pad of the training-time entropy net.  Interior copy; halo rows lerped from the neighbouring
+// tile through the causal table (pconv_host_causal_table: column -2 = no source, -1 = only the
+// second tap) -- no pole mirroring; the first `pad` valid columns re-appear after the last one,
+// the left halo columns stay zero.  One workgroup per output row at a time.
+__global__ __launch_bounds__(kBlock) void entropy_pad_kernel(
+    const float *__restrict__ in, float *__restrict__ out, const int32_t *__restrict__ widths,
+    const int32_t *__restrict__ col, const float *__restrict__ wgt, int c, int h, int w, int pad, int npart,
+    long long nrows) {
+  const int oh = h + 2 * pad, ow = w + 2 * pad;
+  const int rows_all = h * npart;
+  for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int r = (int)(row % oh);
+    const long long tc = row / oh;  // tile-batch * c + channel
+    const int pc = (int)(tc % c);
+    const long long tb = tc / c;
+    const int tg = (int)(tb % npart);
+    const long long img = tb / npart;
+    const int valid = widths[tg];
+    float *dst = out + (size_t)row * ow;
+    const bool interior = (r >= pad) && (r < pad + h);
+    const float *src = nullptr;
+    const int32_t *ecol = nullptr;
+    const float *ewgt = nullptr;
+    int svalid = 1;
+    if (interior) {
+      src = in + ((size_t)tc * h + (r - pad)) * w;
+    } else {
+      const int side = (r < pad) ? 0 : 1;
+      const int rr = side ? r - pad - h : r;
+      const int srow = side ? (tg + 1) * h + rr : tg * h - pad + rr;
+      if (srow >= 0 && srow < rows_all) {
+        const int st = srow / h;
+        svalid = widths[st];
+        src = in + (((size_t)(img * npart + st) * c + pc) * h + (srow - st * h)) * w;
+        const int e = (tg * 2 + side) * pad + rr;
+        ecol = col + (size_t)e * w;
+        ewgt = wgt + (size_t)e * w;
+      }
+    }
+    for (int j = threadIdx.x; j < ow; j += kBlock) {
+      int i = j - pad;
+      if (i >= valid && i < valid + pad) i -= valid;  // right wrap
+      float v = 0.f;
+      if (src && i >= 0 && i < valid && j < valid + 2 * pad) {
+        if (interior) {
+          v = src[i];
+        } else {
+          const int q = ecol[i];
+          if (q != -2) {
+            const float t = ewgt[i];
+            int q1 = q + 1;
+            q1 = (q1 >= svalid) ? q1 - svalid : q1;
+            const float a = q >= 0 ? src[q] : 0.f;
+            v = a * t + src[q1] * (1 - t);
+          }
+        }
+      }
+      dst[j] = v;
+    }
   }
 }
 
@@ -213,8 +278,8 @@ extern "C" int pconv_pseudo_pad_backward(const float *gout, float *gin, const in
   PCONV_REQUIRE(tn > 0 && tn % npart == 0 && c > 0 && h > 0 && w > 0 && pad > 0, "pseudo_pad_backward: bad shape");
   PCONV_REQUIRE((long long)(h + 2 * pad) * w < (1 << 24) && npart <= 128, "pseudo_pad_backward: tile too large for the packed table");
   const long long total = (long long)tn * c * h * w;
-  hipLaunchKernelGGL(pad_backward_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), gout, gin,
-                     widths, rev_start, rev_dst, rev_wgt, c, h, w, npart, pad, total);
+  hipLaunchKernelGGL(pad_backward_kernel<false>, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), gout,
+                     gin, widths, rev_start, rev_dst, rev_wgt, c, h, w, npart, pad, total);
   PCONV_LAUNCH_CHECK("pseudo_pad_backward");
   return PCONV_OK;
 }
@@ -226,5 +291,30 @@ extern "C" int pconv_context_reshape_backward(const float *top, float *bottom, i
   hipLaunchKernelGGL(context_reshape_backward_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream),
                      top, bottom, h * w, c, c / ngroup, total);
   PCONV_LAUNCH_CHECK("context_reshape_backward");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_entropy_pad(const float *in, float *out, const int32_t *widths, const int32_t *col,
+                                 const float *wgt, int tn, int c, int h, int w, int pad, int npart, void *stream) {
+  PCONV_REQUIRE(in && out && widths && col && wgt, "entropy_pad: null pointer");
+  PCONV_REQUIRE(tn > 0 && tn % npart == 0 && c > 0 && h > 0 && w > 0 && pad > 0, "entropy_pad: bad shape");
+  const long long nrows = (long long)tn * c * (h + 2 * pad);
+  const unsigned grid = (unsigned)(nrows < 256 * 32 ? nrows : 256 * 32);
+  hipLaunchKernelGGL(entropy_pad_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), in, out, widths, col, wgt, c,
+                     h, w, pad, npart, nrows);
+  PCONV_LAUNCH_CHECK("entropy_pad");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_entropy_pad_backward(const float *gout, float *gin, const int32_t *widths,
+                                          const int32_t *rev_start, const int32_t *rev_dst, const float *rev_wgt,
+                                          int tn, int c, int h, int w, int pad, int npart, void *stream) {
+  PCONV_REQUIRE(gout && gin && widths && rev_start && rev_dst && rev_wgt, "entropy_pad_backward: null pointer");
+  PCONV_REQUIRE(tn > 0 && tn % npart == 0 && c > 0 && h > 0 && w > 0 && pad > 0, "entropy_pad_backward: bad shape");
+  PCONV_REQUIRE((long long)(h + 2 * pad) * w < (1 << 24) && npart <= 128, "entropy_pad_backward: tile too large for the packed table");
+  const long long total = (long long)tn * c * h * w;
+  hipLaunchKernelGGL(pad_backward_kernel<true>, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), gout,
+                     gin, widths, rev_start, rev_dst, rev_wgt, c, h, w, npart, pad, total);
+  PCONV_LAUNCH_CHECK("entropy_pad_backward");
   return PCONV_OK;
 }

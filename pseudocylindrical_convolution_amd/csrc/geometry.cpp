@@ -218,6 +218,55 @@ extern "C" int pconv_host_pad_reverse(const int32_t *widths, int npart, int heig
   return total;
 }
 
+// Reverse of pconv_host_causal_table for PseudoEntropyPad's backward (same record format as
+// pconv_host_pad_reverse).  Taps of weight exactly 0 are left out, as in the reference's lists
+// (pseudo_entropy_context_cuda.cu:171-209).
+extern "C" int pconv_host_entropy_pad_table(const int32_t *widths, int npart, int height, int width, int pad,
+                                            int version, int32_t *col, float *wgt);
+
+extern "C" int pconv_host_causal_reverse(const int32_t *widths, int npart, int height, int width, int pad,
+                                         int version, int32_t *rev_start, int32_t *rev_dst, float *rev_wgt) {
+  PCONV_REQUIRE(widths && rev_start && rev_dst && rev_wgt, "causal_reverse: null pointer");
+  PCONV_REQUIRE(pad > 0 && height > 0 && (long long)(height + 2 * pad) * width < (1 << 24) && npart <= 128,
+                "causal_reverse: bad pad/height");
+  const size_t n = (size_t)npart * 2 * pad * width;
+  std::vector<int32_t> col(n);
+  std::vector<float> wgt(n);
+  int rc = pconv_host_entropy_pad_table(widths, npart, height, width, pad, version, col.data(), wgt.data());
+  if (rc < 0) return rc;
+  const int rows = height * npart;
+  const size_t keys = (size_t)rows * width;
+  std::vector<std::vector<std::pair<int32_t, float>>> lists(keys);
+  for (int t = 0; t < npart; t++)
+    for (int side = 0; side < 2; side++)
+      for (int r = 0; r < pad; r++) {
+        const int srow = side ? (t + 1) * height + r : t * height - pad + r;
+        if (srow < 0 || srow >= rows) continue;
+        const int prow = side ? height + pad + r : r;
+        const int ws = widths[srow / height];
+        const size_t base = ((size_t)(t * 2 + side) * pad + r) * width;
+        for (int i = 0; i < widths[t]; i++) {
+          const int c0 = col[base + i];
+          if (c0 == -2) continue;
+          const float tw = wgt[base + i];
+          const int32_t dst = (t << 24) | (prow * width + i);
+          if (c0 >= 0 && tw > 0) lists[(size_t)srow * width + c0].push_back({dst, tw});
+          if (tw < 1) lists[(size_t)srow * width + (c0 + 1) % ws].push_back({dst, 1.f - tw});
+        }
+      }
+  int total = 0;
+  for (size_t k = 0; k < keys; k++) {
+    rev_start[k] = total;
+    for (auto &p : lists[k]) {
+      rev_dst[total] = p.first;
+      rev_wgt[total] = p.second;
+      total++;
+    }
+  }
+  rev_start[keys] = total;
+  return total;
+}
+
 extern "C" int pconv_host_wavefront(const int32_t *widths, int npart, int height, int width,
                                     int32_t *order, int32_t *plane_start) {
   PCONV_REQUIRE(widths && order && plane_start, "wavefront: null pointer");
@@ -278,6 +327,41 @@ extern "C" int pconv_host_causal_table(const int32_t *widths, int npart, int hei
           int c;
           float w;
           if (!causal_columns(i, widths[t], widths[row / height], &c, &w)) continue;
+          col[base + i] = c;
+          wgt[base + i] = w;
+        }
+      }
+  return PCONV_OK;
+}
+
+// Table of the training-time causal pad (PseudoEntropyContextOp, pseudo_entropy_context_cuda.cu:51-170):
+// same layout as pconv_host_causal_table.  version 1 is that very table; version 0 keeps both taps unless the
+// next source column lies at or right of the destination column on the full-width grid.
+extern "C" int pconv_host_entropy_pad_table(const int32_t *widths, int npart, int height, int width, int pad,
+                                            int version, int32_t *col, float *wgt) {
+  PCONV_REQUIRE(version == 0 || version == 1, "entropy_pad_table: undefined context version");
+  if (version == 1) return pconv_host_causal_table(widths, npart, height, width, pad, col, wgt);
+  PCONV_REQUIRE(widths && col && wgt && pad >= 1, "entropy_pad_table: bad argument");
+  const int rows = height * npart;
+  for (int t = 0; t < npart; t++)
+    for (int side = 0; side < 2; side++)
+      for (int r = 0; r < pad; r++) {
+        const int row = (side == 0) ? t * height - pad + r : (t + 1) * height + r;
+        const size_t base = ((size_t)(t * 2 + side) * pad + r) * width;
+        for (int i = 0; i < width; i++) {
+          col[base + i] = -2;
+          wgt[base + i] = 0.f;
+          if (row < 0 || row >= rows || i >= widths[t]) continue;
+          const int ws = widths[row / height];
+          const float p = facing_column(i, widths[t], ws, false);
+          const int c = p < 0 ? -1 : static_cast<int>(p);
+          float w = c + 1 - p;
+          const float next_full = (c + 1 + 0.5) / ws * width - 0.5;
+          const float here_full = (i + 0.5) / widths[t] * width - 0.5;
+          if (next_full >= static_cast<int>(here_full) + 0.999)
+            w = 1.f;
+          else if (c == -1)
+            w = 0.f;
           col[base + i] = c;
           wgt[base + i] = w;
         }

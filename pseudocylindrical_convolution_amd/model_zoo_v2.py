@@ -11,10 +11,14 @@ import os
 import torch
 from torch import nn
 
-from .PCONV_operator import Dtow, PseudoContextV2, PseudoFillV2, PseudoGDNV2, PseudoPadV2, backend
+from .PCONV_operator import (ContextReshape, DropGrad, Dtow, EntropyGmm, Extract, MaskConv2, PseudoContextV2,
+                             PseudoEntropyContext, PseudoEntropyPad, PseudoFillV2, PseudoGDNV2, PseudoPadV2,
+                             PseudoQUANTV2, SphereSlice, SphereUslice, StubMask, backend)
 
 __all__ = ["ClipData", "TileConv2d", "ResidualBlock", "AttentionBlock", "ResidualBlockV2", "ResidualBlockDown",
-           "SphereConv2", "EncoderV2", "ResidualBlockUp", "SphereConvOld", "DecoderV2"]
+           "SphereConv2", "EncoderV2", "ResidualBlockUp", "SphereConvOld", "DecoderV2", "EntropyConv",
+           "EntropyResidualBlock", "EntropySubNet", "EntropyNet", "CMPNetV2MF", "CMPNetV2M", "CMPNetV2MFExtractor",
+           "CMPNetV2Decoder", "CMPNetV2MFEntropy", "AccGrad"]
 
 
 class _LeakyClip(torch.autograd.Function):
@@ -68,6 +72,10 @@ class TileConv2d(nn.Conv2d):
         ops = backend.ops()
         slope = prelu.weight if prelu is not None else None
         vendor = os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d")
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            # training: the convolution and its activation go through autograd's library
+            # kernels, as the reference's nn.Conv2d does; the tile ops around them use their own backward
+            vendor, live = True, None
         fused = (not vendor) and getattr(ops, "FUSED_EPILOGUE", False)
         limit, npart = None, 0
         if live is not None and hasattr(ops, "conv_col_limit") and os.environ.get("PCONV_SKIP_DEAD", "1") == "1":
@@ -295,3 +303,214 @@ class DecoderV2(nn.Module):
             x = m(x)
         # 3x3 conv to 12 channels + the depth-to-width that makes them 3 at full size
         return mods[-2](x, (self.ctx, x.shape[3] - 2), d2w=mods[-1])
+
+
+# --------------------------------------------------------------------------
+# training-time networks: the whole-tensor entropy model and the end-to-end codec
+# --------------------------------------------------------------------------
+class EntropyConv(nn.Module):
+    """causal pad -> 5x5 conv masked to the 3-D causal neighbourhood -> PReLU -> trim
+    (reference: model_zoo_v2.py:214-228)."""
+
+    def __init__(self, ngroups, cin, cout, hidden, npart, ctx, device_id, act=True):
+        super(EntropyConv, self).__init__()
+        self.pad = PseudoEntropyPad(2, npart, ctx, device=device_id)
+        self.conv = MaskConv2(ngroups, cin, cout, 5, hidden, device_id)
+        self.trim = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.act = nn.PReLU(ngroups * cout) if act else None
+
+    def forward(self, x):
+        y = self.conv(self.pad(x))
+        if self.act is not None:
+            y = self.act(y)
+        return self.trim(y)
+
+
+class EntropyResidualBlock(nn.Module):
+    """(reference: model_zoo_v2.py:230-239)"""
+
+    def __init__(self, ngroups, cpn, npart, ctx, device_id=0):
+        super(EntropyResidualBlock, self).__init__()
+        self.conv1 = EntropyConv(ngroups, cpn, cpn, True, npart, ctx, device_id, True)
+        self.conv2 = EntropyConv(ngroups, cpn, cpn, True, npart, ctx, device_id, True)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x)) + x
+
+
+class EntropySubNet(nn.Module):
+    """one of the three GMM parameter networks; net_type 0 = weights (softmax), 1 = means,
+    2 = scales (ReLU, output bias 2) (reference: model_zoo_v2.py:241-270).  Output (N*G*H*W, K)."""
+
+    def __init__(self, ngroups, cpn, npart, num_gaussian, net_type, ctx, device_id):
+        super(EntropySubNet, self).__init__()
+        block = lambda: EntropyResidualBlock(ngroups, cpn, npart, ctx, device_id)
+        self.net = nn.Sequential(
+            EntropyConv(ngroups, 1, cpn, False, npart, ctx, device_id),
+            block(), block(), block(), block(), block(),
+            EntropyConv(ngroups, cpn, num_gaussian, True, npart, ctx, device_id, False),
+        )
+        self.reshape = ContextReshape(ngroups, device_id)
+        self.act = None
+        if net_type == 0:
+            self.act = nn.Softmax(dim=1)
+        elif net_type == 2:
+            self.act = nn.ReLU()
+            self.net[6].conv.bias.data.fill_(2)
+
+    def forward(self, x):
+        y = self.reshape(self.net(x))
+        return self.act(y) if self.act is not None else y
+
+
+class EntropyNet(nn.Module):
+    """rate of every code symbol under its causal GMM, and the mask of the symbols that exist
+    (reference: model_zoo_v2.py:272-301)."""
+
+    def __init__(self, ngroups, npart, ctx, cpn=3, num_gaussian=3, device_id=0, drop_flag=False):
+        super(EntropyNet, self).__init__()
+        self.drop = DropGrad(drop_flag)
+        self.weight_net = EntropySubNet(ngroups, cpn, npart, num_gaussian, 0, ctx, device_id)
+        self.mean_net = EntropySubNet(ngroups, cpn, npart, num_gaussian, 1, ctx, device_id)
+        self.delta_net = EntropySubNet(ngroups, cpn, npart, num_gaussian, 2, ctx, device_id)
+        self.mask = None
+        self.fill = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.fill2 = PseudoFillV2(0, npart, ctx, device=device_id)
+        self.ent_loss = EntropyGmm(num_gaussian, device=device_id)
+
+    def setup_mask(self, x):
+        with torch.no_grad():
+            self.mask = self.fill(torch.ones_like(x).detach()).view(-1)
+
+    def forward(self, x):
+        self.setup_mask(x)
+        x = self.drop(self.fill2(x))
+        weight = self.weight_net(x)
+        mean = self.mean_net(x)
+        delta = self.delta_net(x) + 1e-6
+        loss_vec = self.ent_loss(weight, delta, mean, x.view(-1, 1))
+        return loss_vec * self.mask, self.mask
+
+
+class CMPNetV2MF(nn.Module):
+    """end-to-end training graph: reconstruction, per-symbol rate, symbol mask
+    (reference: model_zoo_v2.py:304-334)."""
+
+    def __init__(self, valid_dim=162, channels=192, code_channels=192, npart=16, quant_levels=8, opt=False,
+                 init=False, device_id=0):
+        super(CMPNetV2MF, self).__init__()
+        self.slice = SphereSlice(npart, pad=0, opt=opt, device=device_id)
+        self.uslice = SphereUslice(npart, pad=0, opt=opt, device=device_id)
+        self.ctx = PseudoContextV2(npart, opt, device=device_id)
+        self.ctx_ent = PseudoEntropyContext(npart, 1, opt, device=device_id)
+        self.encoder = EncoderV2(channels, code_channels, npart, self.ctx, device_id)
+        self.decoder = DecoderV2(channels, code_channels, npart, self.ctx, device_id)
+        self.quant = PseudoQUANTV2(code_channels, quant_levels, npart, self.ctx, top_alpha=0.0001,
+                                   device_id=device_id, ntop=2)
+        self.vm = StubMask(valid_dim)
+        self.ext = Extract(valid_dim)
+        self.clip = ClipData()
+        self.ent = EntropyNet(valid_dim // 4, npart, self.ctx_ent, 3, 3, device_id, drop_flag=init)
+        self.mean_val = (quant_levels - 1) / 2.
+        self.dtw = Dtow(2, True, device_id)
+
+    def forward(self, x):
+        code = self.encoder(self.slice(x))
+        code_f, code_i = self.quant(code)
+        code_f = code_f * self.vm(code_f)
+        y = self.uslice(self.decoder(code_f))
+        symbols = self.dtw(self.ext(code_i)) - self.mean_val
+        ent_vec, mask = self.ent(symbols)
+        return self.clip(y), ent_vec, mask
+
+
+class CMPNetV2M(nn.Module):
+    """the transforms and the quantiser without the entropy model.  test/trainDDP_Base.py:109 builds
+    `model_zoo_v2.CMPNetV2M`, which the reference's model_zoo_v2.py does not define; this is the
+    CMPNetV2MF graph up to the reconstruction, same sub-module names (its checkpoints initialise
+    CMPNetV2MF through init_with_trained_model)."""
+
+    def __init__(self, valid_dim=162, channels=192, code_channels=192, npart=16, quant_levels=8, opt=False,
+                 init=False, device_id=0):
+        super(CMPNetV2M, self).__init__()
+        self.slice = SphereSlice(npart, pad=0, opt=opt, device=device_id)
+        self.uslice = SphereUslice(npart, pad=0, opt=opt, device=device_id)
+        self.ctx = PseudoContextV2(npart, opt, device=device_id)
+        self.encoder = EncoderV2(channels, code_channels, npart, self.ctx, device_id)
+        self.decoder = DecoderV2(channels, code_channels, npart, self.ctx, device_id)
+        self.quant = PseudoQUANTV2(code_channels, quant_levels, npart, self.ctx, top_alpha=0.0001,
+                                   device_id=device_id, ntop=2)
+        self.vm = StubMask(valid_dim)
+        self.clip = ClipData()
+
+    def forward(self, x):
+        code_f, _ = self.quant(self.encoder(self.slice(x)))
+        code_f = code_f * self.vm(code_f)
+        return self.clip(self.uslice(self.decoder(code_f)))
+
+
+class CMPNetV2MFExtractor(nn.Module):
+    """image -> the symbol tensor the entropy model sees (reference: model_zoo_v2.py:336-354)."""
+
+    def __init__(self, valid_dim=162, channels=192, code_channels=192, npart=16, quant_levels=8, opt=False,
+                 init=False, device_id=0):
+        super(CMPNetV2MFExtractor, self).__init__()
+        self.slice = SphereSlice(npart, pad=0, opt=opt, device=device_id)
+        self.ctx = PseudoContextV2(npart, opt, device=device_id)
+        self.encoder = EncoderV2(channels, code_channels, npart, self.ctx, device_id)
+        self.quant = PseudoQUANTV2(code_channels, quant_levels, npart, self.ctx, top_alpha=0.0001,
+                                   device_id=device_id, ntop=2)
+        self.ext = Extract(valid_dim)
+        self.mean_val = (quant_levels - 1) / 2.
+        self.dtw = Dtow(2, True, device_id)
+
+    def forward(self, x):
+        _, code_i = self.quant(self.encoder(self.slice(x)))
+        return self.dtw(self.ext(code_i))
+
+
+class CMPNetV2Decoder(nn.Module):
+    """de-quantised code -> image (reference: model_zoo_v2.py:356-368)."""
+
+    def __init__(self, channels=192, code_channels=192, npart=16, opt=False, init=False, device_id=0):
+        super(CMPNetV2Decoder, self).__init__()
+        self.uslice = SphereUslice(npart, pad=0, opt=opt, device=device_id)
+        self.ctx = PseudoContextV2(npart, opt, device=device_id)
+        self.decoder = DecoderV2(channels, code_channels, npart, self.ctx, device_id)
+        self.clip = ClipData()
+
+    def forward(self, x):
+        return self.clip(self.uslice(self.decoder(x)))
+
+
+class CMPNetV2MFEntropy(nn.Module):
+    """the entropy model on its own (reference: model_zoo_v2.py:370-381)."""
+
+    def __init__(self, valid_dim=162, channels=192, code_channels=192, npart=16, quant_levels=8, opt=False,
+                 init=False, device_id=0):
+        super(CMPNetV2MFEntropy, self).__init__()
+        self.ctx = PseudoEntropyContext(npart, 1, opt, device=device_id)
+        self.ent = EntropyNet(valid_dim // 4, npart, self.ctx, 3, 3, device_id, drop_flag=init)
+        self.mean_val = (quant_levels - 1) / 2.
+
+    def forward(self, x):
+        return self.ent(x - self.mean_val)
+
+
+class AccGrad():
+    """gradient accumulator over `acc_batch` steps (reference: model_zoo_v2.py:383-402)."""
+
+    def __init__(self, params):
+        self.acc_grad = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in list(params)]
+        self.num_param = len(self.acc_grad)
+
+    def zero(self):
+        for g in self.acc_grad:
+            g.zero_()
+
+    def acc(self, params):
+        torch._foreach_add_(self.acc_grad, [p.grad for p in list(params)])
+
+    def copy_back(self, param):
+        torch._foreach_add_([p.grad for p in list(param)], self.acc_grad)
+        self.zero()

@@ -131,3 +131,42 @@ def test_projects_backward_is_the_transpose(near):
     _adjoint(lambda t: op.forward(t)[0], lambda g: op.backward(g)[0], x, (28, 3, 19, 28))
     cnt = op.backward(torch.ones(28, 3, 19, 28))[1]
     assert abs(cnt.sum().item() - 28 * 3 * 19 * 28) < 1.0     # the bilinear weights of a sample sum to 1
+
+
+@pytest.mark.parametrize("shape,pad,version", [((32, 2, 4, 128), 2, 1), ((16, 3, 2, 64), 2, 1), ((16, 1, 8, 256), 1, 1),
+                                               ((16, 2, 4, 128), 2, 0)])
+def test_entropy_pad_is_causal_and_its_backward_is_the_transpose(shape, pad, version):
+    """PseudoEntropyPadOp (pseudo_entropy_pad_cuda.cu): halo column j of a tile reads only source
+    columns <= j (version 1), the left halo columns and the pole rows are zero, the first `pad`
+    columns re-appear after the last valid one, and backward is the exact transpose"""
+    ctx = O.PseudoEntropyContextOp(16, 20, version, W16)
+    op = O.PseudoEntropyPadOp(pad, 16, ctx.addr())
+    tn, c, h, w = shape
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(7))
+    xz = O.PseudoFillOp(0, 16, 0, 0, ctx.addr(), 1).forward(x.clone())[0]
+    gshape = (tn, c, h + 2 * pad, w + 2 * pad)
+    gx = _adjoint(lambda t: op.forward(t)[0], lambda g: op.backward(g)[0], xz, gshape)
+    widths = O.widths_v3(W16, 16, 16 * h, w)
+    y = op.forward(xz)[0].clone()
+    assert y[:, :, :, :pad].abs().max().item() == 0
+    assert y[0::16, :, :pad].abs().max().item() == 0 and y[15::16, :, h + pad:].abs().max().item() == 0
+    for t in range(16):
+        v = int(widths[t])
+        assert torch.equal(y[t::16, :, pad:pad + h, pad:pad + v], xz[t::16, :, :, :v])
+        assert torch.equal(y[t::16, :, :, pad + v:2 * pad + v], y[t::16, :, :, pad:2 * pad])
+        assert y[t::16, :, :, 2 * pad + v:].abs().sum().item() == 0
+        if v < w:
+            assert gx[t::16, :, :, v:].abs().max().item() == 0
+    if version == 1:
+        # causality: perturbing source column k changes no halo value left of column k of the reader
+        k = 5
+        xp = xz.clone()
+        xp[:, :, :, k:] += 1.0
+        xp = O.PseudoFillOp(0, 16, 0, 0, ctx.addr(), 1).forward(xp)[0]
+        yp = op.forward(xp)[0]
+        assert torch.equal(yp[:, :, :pad, pad:pad + k], y[:, :, :pad, pad:pad + k])
+        assert torch.equal(yp[:, :, h + pad:, pad:pad + k], y[:, :, h + pad:, pad:pad + k])
+    g = torch.randn(gshape, generator=torch.Generator().manual_seed(8))
+    g0 = g.clone()
+    op.backward(g)
+    assert torch.equal(g, g0)

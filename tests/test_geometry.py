@@ -164,3 +164,50 @@ def test_project_table_equals_oracle():
     assert xy[..., 0].min() >= 0 and xy[..., 0].max() <= 1023 and xy[..., 1].min() >= 0 and xy[..., 1].max() <= 511
     centre = xy[1, 85, 127:129].mean(0)                      # viewport (theta 0, phi 0) looks at the ERP centre
     assert abs(centre[0] - 511.5) < 1.0 and abs(centre[1] - 255.5) < 1.0
+
+
+@pytest.mark.parametrize("h,w,pad,version", [(4, 128, 2, 1), (2, 64, 2, 0), (16, 512, 2, 1), (8, 256, 1, 0),
+                                             (32, 1024, 2, 1)])
+def test_entropy_pad_table_and_its_reverse(h, w, pad, version):
+    """training-time causal pad: the host table equals the oracle's restatement of
+    pseudo_entropy_context_cuda.cu for both context versions, version 1 is the table the inference
+    path pads with, and the reverse CSR holds exactly the taps with a non-zero weight"""
+    wd = widths(W16, 16, 16 * h, w)
+    n = 16 * 2 * pad
+    col, wgt = np.zeros(n * w, np.int32), np.zeros(n * w, np.float32)
+    call("pconv_host_entropy_pad_table", P(wd), 16, h, w, pad, version, P(col), P(wgt))
+    channel = 2
+    h2 = np.zeros(n, np.int32)
+    dst, src = np.zeros(n * w, np.int64), np.zeros(n * w, np.int64)
+    pcol, pt = np.zeros(n * w, np.int32), np.zeros(n * w, np.float32)
+    O.lib().orc_pseudo_entropy_context(O._p(wd), O._p(h2), O._p(dst), O._p(src), O._p(pcol), O._p(pt), O.I(channel),
+                                       O.I(h), O.I(w), O.I(16), O.I(pad), O.I(version))
+    ntap = 0
+    for e in range(n):
+        t = e // (2 * pad)
+        v = int(wd[t])
+        mine_c, mine_w = col[e * w:e * w + v], wgt[e * w:e * w + v]
+        if h2[e] < 0:
+            assert (mine_c == -2).all()
+            continue
+        # "no source" (-2) stands for the reference's (-1, weight 1): the value is 0 either way
+        theirs_c = np.where((pcol[e * w:e * w + v] == -1) & (pt[e * w:e * w + v] == 1), -2, pcol[e * w:e * w + v])
+        live = mine_c != -2
+        assert (mine_c == (theirs_c if version == 1 else pcol[e * w:e * w + v])).all()
+        assert (mine_w[live] == pt[e * w:e * w + v][live]).all()
+        ntap += int(((mine_c >= 0) & (mine_w > 0) & live).sum()) + int(((mine_w < 1) & live).sum())
+        assert src[e * w] == (int(h2[e]) * channel * h + (src[e * w] // w) % h) * w
+    if version == 1:
+        col1, wgt1 = np.zeros(n * w, np.int32), np.zeros(n * w, np.float32)
+        call("pconv_host_causal_table", P(wd), 16, h, w, pad, P(col1), P(wgt1))
+        assert (col1 == col).all() and (wgt1 == wgt).all()
+    start = np.zeros(16 * h * w + 1, np.int32)
+    rdst, rw = np.zeros(4 * 16 * pad * w, np.int32), np.zeros(4 * 16 * pad * w, np.float32)
+    total = call("pconv_host_causal_reverse", P(wd), 16, h, w, pad, version, P(start), P(rdst), P(rw))
+    assert total == ntap == start[-1]
+    assert (np.diff(start) >= 0).all() and (rw[:total] > 0).all() and (rw[:total] <= 1).all()
+    # every destination's weights sum to one unless its first tap is missing
+    sums = {}
+    for k in range(total):
+        sums[int(rdst[k])] = sums.get(int(rdst[k]), 0.0) + float(rw[k])
+    assert max(sums.values()) <= 1 + 1e-6

@@ -73,6 +73,29 @@ def test_pad_backward(shape, pad):
     assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
 
 
+@pytest.mark.parametrize("shape,pad,version", [((16, 4, 16, 512), 2, 1), ((32, 3, 8, 256), 2, 1), ((16, 2, 2, 64), 2, 1),
+                                               ((16, 2, 4, 128), 1, 0), ((16, 9, 64, 1024), 2, 1)])
+def test_entropy_pad_forward_backward(shape, pad, version):
+    """PseudoEntropyPadOp: forward bit-exact (one fmul/fmul/fadd per halo value, no contraction on
+    either side), backward within 1e-5, and <A x, g> == <x, A^T g> on the device"""
+    g = torch.Generator().manual_seed(13)
+    gctx, octx = P().PseudoEntropyContextOp(16, 20, version, W16, 0, False), O.PseudoEntropyContextOp(16, 20, version, W16)
+    gop, cop = P().PseudoEntropyPadOp(pad, 16, gctx.addr(), 0, False), O.PseudoEntropyPadOp(pad, 16, octx.addr())
+    x = torch.randn(*shape, generator=g)                # dead columns left dirty: both sides ignore them
+    yg, yc = gop.forward(x.to(DEV))[0], cop.forward(x)[0]
+    close(yg, yc, 1e-6)
+    grad = torch.randn(yc.shape, generator=g)
+    gd = grad.to(DEV)
+    gg, gc = gop.backward(gd)[0], cop.backward(grad)[0]
+    close(gg, gc)
+    assert torch.equal(gd.cpu(), grad)
+    xz = O.PseudoFillOp(0, 16, 0, 0, octx.addr(), 1).forward(x.clone())[0].to(DEV)
+    yz = gop.forward(xz)[0]
+    lhs = (yz.double() * gd.double()).sum().item()
+    rhs = (xz.double() * gg.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+
+
 def test_context_reshape_dtow_gmm_backward():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 42, 5, 7, generator=g)
