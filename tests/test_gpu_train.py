@@ -90,3 +90,35 @@ def test_end_to_end_training_steps_on_the_gpu():
     with torch.no_grad():
         code = net.encoder(net.slice(x[:1]))
         assert code.shape == (16, 192, 2, 64) and torch.isfinite(code).all()
+
+
+def test_exported_checkpoint_codes_at_the_predicted_rate_on_the_engine(tmp_path):
+    """the benchmark's model (valid_dim 56): rate predicted by the whole-tensor EntropyNet on the
+    GPU vs the bytes the native entropy engine writes, and decode == the training graph's output"""
+    import math
+    from pseudocylindrical_convolution_amd import export, model_zoo_v2 as Z, pseudo_codec as PC
+    backend.reset()
+    torch.manual_seed(0)
+    vd = 56
+    net = Z.CMPNetV2MF(vd, 192, 192, 16, 8, True, False, 0).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p in net.ent.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(DEV))
+        net.ent.delta_net.net[6].conv.bias.fill_(1.0)
+    net.eval()
+    x = torch.rand(1, 3, 512, 1024, generator=g).to(DEV)
+    with torch.no_grad():
+        y, ent, mask = net(x)
+    bits = ent.sum().item() / math.log(2)
+    paths = export.export_codec(net, vd, str(tmp_path), "t")
+    enc, dec = PC.PseudoEncoder(vd, 0).to(DEV), PC.PseudoDecoder(vd, 0).to(DEV)
+    PC.load_models(enc, paths[0], paths[2], DEV)
+    PC.load_models(dec, paths[1], paths[2], DEV)
+    code = str(tmp_path / "code.bin")
+    enc(x, code)
+    coded = os.path.getsize(code) * 8
+    assert mask.sum().item() == 13376 * 7
+    assert -8 <= coded - bits <= 0.002 * bits + 40, (coded, bits)
+    out = dec(code, 512, 1024)
+    assert (out - y).abs().max().item() <= 1e-4

@@ -173,3 +173,43 @@ def test_two_rank_ddp_training_job(tmp_path):
     assert any(k.startswith("ent.weight_net.net.0.conv.weight") for k in sd) and "quant.count" in sd
     log = open(os.path.join(str(tmp_path), "save_models", "ent_normal_16_8_16_logs_0.txt")).read()
     assert "Train Epoch: 1" in log and "Train Epoch: 2" in log and "Test set:" in log
+
+
+@pytest.mark.timeout(600)
+def test_exported_checkpoint_codes_at_the_rate_the_training_graph_predicts(oracle_backend, tmp_path):
+    """train-time graph -> export -> the codec: the three files load with strict=True, the code file
+    is as long as the whole-tensor entropy model says (sum of -log2 p, + the coder's closing bytes),
+    and decoding reproduces the training graph's reconstruction bit for bit.  Two independent
+    restatements meet here: masked whole-tensor convolutions with the causal pad, and the wavefront
+    engine ops with their causal halo lists."""
+    import math
+    from pseudocylindrical_convolution_amd import export, model_zoo_v2 as Z, pseudo_codec as PC
+    torch.manual_seed(0)
+    vd = 8
+    net = Z.CMPNetV2MF(vd, 192, 192, 16, 8, True, False, 0)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p in net.ent.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        net.ent.delta_net.net[6].conv.bias.fill_(1.0)
+    net.eval()
+    x = torch.rand(1, 3, 512, 1024, generator=g)
+    with torch.no_grad():
+        y, ent, mask = net(x)
+    bits = ent.sum().item() / math.log(2)
+    paths = export.export_codec(net, vd, str(tmp_path), "t")
+    enc, dec = PC.PseudoEncoder(vd, 0), PC.PseudoDecoder(vd, 0)
+    PC.load_models(enc, paths[0], paths[2], "cpu")                       # strict
+    PC.load_models(dec, paths[1], paths[2], "cpu")
+    code = str(tmp_path / "code.bin")
+    enc(x, code)
+    coded = os.path.getsize(code) * 8
+    assert mask.sum().item() == 13376
+    assert -8 <= coded - bits <= 0.002 * bits + 40, (coded, bits)
+    assert torch.equal(dec(code, 512, 1024), y)
+    # a DDP-style state dict ("module." prefix) exports the same tensors
+    wrapped = {"module." + k: v for k, v in net.state_dict().items()}
+    again = export.export_codec(wrapped, vd, str(tmp_path / "b"), "t")
+    a, b = torch.load(paths[2]), torch.load(again[2])
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert a["ent.net.0.conv.weight"].shape == (3, 6, 2, 5, 5)
