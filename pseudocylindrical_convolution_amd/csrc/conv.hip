@@ -57,6 +57,21 @@ struct ConvCfg {
   static constexpr int STAGE = XSZ + WSZ;
   static constexpr int XLD = (XSZ + THREADS - 1) / THREADS;        // floats / thread
   static constexpr int WLD = (WSZ / 4 + THREADS - 1) / THREADS;    // float4 / thread
+  static constexpr int MTv = MT, NTv = NT, KSv = KS;
+  // patch offset (floats) of reduction entry k = (ci*KS + kh)*KS + kw inside a chunk
+  static constexpr int patch_off(int k) {
+    return (k / (KS * KS)) * P::PR * P::PC + ((k / KS) % KS) * P::PC + (k % KS);
+  }
+  // the two lane halves of an MFMA take entries 2kp and 2kp+1: their patch offsets differ by one
+  // of ND values (next column / next row / next channel), one LDS base register each
+  static constexpr int ND = (KS == 1) ? 1 : 3;
+  static constexpr int delta(int i) {
+    return KS == 1 ? P::PR * P::PC : (i == 0 ? 1 : (i == 1 ? P::PC - (KS - 1) : P::PR * P::PC - (KS - 1) * P::PC - (KS - 1)));
+  }
+  static constexpr int delta_index(int kp) {
+    const int d = patch_off(2 * kp + 1) - patch_off(2 * kp);
+    return d == delta(0) ? 0 : (d == delta(1) ? 1 : 2);
+  }
   static_assert((WN * NT) % 2 == 0, "pixel tile is whole rows of two 32-column segments");
   static_assert(KK % 2 == 0, "chunk reduction length must be even");
   static_assert(BM % 4 == 0, "weight slab rows are float4 multiples");
@@ -190,6 +205,146 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
   }
 }
 
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+// LDS-DMA of one chunk (input patch + weight slab): XLD patch dwords, then WLD weight float4s per
+// thread, all issued at the head of the previous chunk's matrix loop.  (Issuing them one piece every
+// second k-pair instead -- so that the ~30 KB do not come back in one burst -- measured 1.5 % slower.)
+template <class C>
+struct ConvStager {
+  using P = typename C::P;
+  static constexpr int PIECES = C::XLD + C::WLD;
+  const float *xb, *wb;  // global bases of the chunk being staged
+  float *xs, *ws;        // its LDS buffer
+  const unsigned (&xoffs)[C::XLD];
+  const unsigned (&woffs)[C::WLD];
+  int tid, wave, tail;
+  long long cs;
+  bool active, ragged;
+
+  template <int J>
+  __device__ __forceinline__ void issue() const {
+    if (!active) return;
+    if constexpr (J < C::XLD) {
+#ifdef PCONV_ABL_NOXDMA
+      return;
+#endif
+      const int e = tid + J * C::THREADS;
+      if (e < C::XSZ) {
+        unsigned off = xoffs[J];
+        if (ragged) {
+          // channels past cin: read the last real one instead -- their rows of the
+          // packed weight are zero, so the product adds +0 to the chain
+          const int ci = e / (P::PC * P::PR);
+          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * cs);
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(xs + J * C::THREADS + wave * 64), 4, 0,
+                                         0);
+      }
+    } else {
+#ifdef PCONV_ABL_NOWDMA
+      return;
+#endif
+      constexpr int JW = J - C::XLD;
+      const int e4 = tid + JW * C::THREADS;
+      if (e4 < C::WSZ / 4)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wb + woffs[JW]),
+                                         (lds_ptr_t *)(ws + (JW * C::THREADS + wave * 64) * 4), 16, 0, 0);
+    }
+  }
+
+  template <int J = 0>
+  __device__ __forceinline__ void issue_all() const {
+    if constexpr (J < PIECES) {
+      issue<J>();
+      issue_all<J + 1>();
+    }
+  }
+};
+
+// LDS operand reads of the matrix loop, issued by hand: `ds_read_b32 dst, base offset:imm` with the
+// whole (chunk-invariant) offset in the immediate -- no address arithmetic in the loop -- and
+// COUNTED waits: before the MFMAs of k-pair kp only the reads of kp must have landed, the MT + NT
+// reads of kp+1 issued after them stay in flight (LDS returns in order).  The compiler's own
+// scoreboard put `s_waitcnt lgkmcnt(0)` in front of every second MFMA block, i.e. waited for the
+// reads it had just issued: their latency -- longer while the LDS-DMA of the next chunk is landing --
+// was exposed once per 6 MFMAs.
+template <int OFF>
+__device__ __forceinline__ float lds_read_imm(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <class C, int KP>
+__device__ __forceinline__ void conv_read_pair(float (&A)[C::MTv], float (&B)[C::NTv], unsigned abase,
+                                               const unsigned (&bbase)[C::NTv][C::ND]) {
+  static_assert(C::MTv <= 3 && C::NTv <= 2, "operand reads are written out for MT <= 3, NT <= 2");
+  constexpr int aoff = 2 * KP * C::BM * 4;
+  A[0] = lds_read_imm<aoff>(abase);
+  if constexpr (C::MTv > 1) A[1] = lds_read_imm<aoff + 128>(abase);
+  if constexpr (C::MTv > 2) A[2] = lds_read_imm<aoff + 256>(abase);
+  constexpr int boff = C::patch_off(2 * KP) * 4, di = C::delta_index(KP);
+  B[0] = lds_read_imm<boff>(bbase[0][di]);
+  if constexpr (C::NTv > 1) B[1] = lds_read_imm<boff>(bbase[1][di]);
+}
+
+// wait until at most PENDING LDS reads are outstanding; the operands pass through the statement so
+// that nothing that uses them can be scheduled above it
+template <int PENDING, int MT, int NT>
+__device__ __forceinline__ void conv_wait_pair(float (&A)[MT], float (&B)[NT]) {
+  if constexpr (MT == 3 && NT == 1)
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B[0]) : "n"(PENDING));
+  else if constexpr (MT == 1 && NT == 1)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A[0]), "+v"(B[0]) : "n"(PENDING));
+  else if constexpr (MT == 3 && NT == 2)
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B[0]), "+v"(B[1]) : "n"(PENDING));
+  else
+    static_assert(MT == 3 || MT == 1, "conv_wait_pair: unsupported tile");
+}
+
+#ifndef PCONV_PREFETCH
+#define PCONV_PREFETCH 1
+#endif
+// operands are read PCONV_PREFETCH k-pairs ahead of the MFMAs that use them, through a ring of
+// PCONV_PREFETCH + 1 register sets
+constexpr int kAhead = PCONV_PREFETCH;
+
+template <class C, bool SQ, int KP>
+__device__ __forceinline__ void conv_chunk_step(f32x16 (&acc)[C::MTv][C::NTv], float (&a)[kAhead + 1][C::MTv],
+                                                float (&b)[kAhead + 1][C::NTv], unsigned abase,
+                                                const unsigned (&bbase)[C::NTv][C::ND]) {
+  constexpr int NP = C::KK / 2, SETS = kAhead + 1;
+  if constexpr (KP + kAhead < NP)
+    conv_read_pair<C, KP + kAhead>(a[(KP + kAhead) % SETS], b[(KP + kAhead) % SETS], abase, bbase);
+  constexpr int ahead = (NP - 1 - KP) < kAhead ? (NP - 1 - KP) : kAhead;  // k-pairs read after this one
+  float(&A)[C::MTv] = a[KP % SETS];
+  float(&B)[C::NTv] = b[KP % SETS];
+  conv_wait_pair<ahead * (C::MTv + C::NTv)>(A, B);
+  if (SQ) {
+#pragma unroll
+    for (int n = 0; n < C::NTv; n++) B[n] = B[n] * B[n];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < C::MTv; m++)
+#pragma unroll
+    for (int n = 0; n < C::NTv; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m], B[n], acc[m][n], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (KP + 1 < NP) conv_chunk_step<C, SQ, KP + 1>(acc, a, b, abase, bbase);
+}
+
+template <class C, int KP>
+__device__ __forceinline__ void conv_chunk_prologue(float (&a)[kAhead + 1][C::MTv], float (&b)[kAhead + 1][C::NTv],
+                                                    unsigned abase, const unsigned (&bbase)[C::NTv][C::ND]) {
+  if constexpr (KP < kAhead && KP < C::KK / 2) {
+    conv_read_pair<C, KP>(a[KP], b[KP], abase, bbase);
+    conv_chunk_prologue<C, KP + 1>(a, b, abase, bbase);
+  }
+}
+
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
@@ -288,99 +443,52 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
   const int tail = cin % KC;  // channels of a ragged last chunk (0: none)
   const size_t xstep = (size_t)KC * vin.cs, wstep = (size_t)C::KK * cout_pad;
 
-  typedef __attribute__((address_space(3))) void lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void glb_ptr_t;
-  auto stage_chunk = [&](int chunk, int buf) {
+  auto stager = [&](int chunk, int buf) {
     float *xs = lds + buf * C::STAGE;
-    float *ws = xs + C::XSZ;
-    const float *xb = inp + chunk * xstep;
-    const bool ragged = tail != 0 && chunk == nchunk - 1;
-#pragma unroll
-    for (int j = 0; j < C::XLD; j++) {
-      const int e = tid + j * kThreads;
-      if (e < C::XSZ) {
-        unsigned off = xoffs[j];
-        if (ragged) {
-          // channels past cin: read the last real one instead -- their rows of the
-          // packed weight are zero, so the product adds +0 to the chain
-          const int ci = e / (P::PC * P::PR);
-          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs);
-        }
-        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(xs + j * kThreads + wave * 64),
-                                         4, 0, 0);
-      }
-    }
-    const float *wb = wp + chunk * wstep + cout0;
-#pragma unroll
-    for (int j = 0; j < C::WLD; j++) {
-      const int e4 = tid + j * kThreads;
-      if (e4 < C::WSZ / 4)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wb + woffs[j]),
-                                         (lds_ptr_t *)(ws + (j * kThreads + wave * 64) * 4), 16, 0, 0);
-    }
+    return ConvStager<C>{inp + chunk * xstep, wp + chunk * wstep + cout0, xs, xs + C::XSZ, xoffs, woffs, tid, wave, tail,
+                         vin.cs, chunk < nchunk, tail != 0 && chunk == nchunk - 1};
   };
 
-  // per-lane LDS bases of the operand fragments
-  int xbase[NT];
+  // per-lane LDS byte addresses of the operand fragments in buffer 0 (see conv_read_pair)
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);  // low half of the flat address = LDS offset
+  unsigned abase = lds0 + (unsigned)(C::XSZ + half * C::BM + wm * MT * 32 + l31) * 4u;
+  unsigned bbase[NT][C::ND];
 #pragma unroll
   for (int n = 0; n < NT; n++) {
-    const int seg = wn * NT + n;  // 0..3: row = seg / 2, 32-column half = seg % 2
+    const int seg = wn * NT + n;  // row = seg / 2, 32-column half = seg % 2 of the workgroup tile
     const int prow = seg >> 1, pcol = (seg & 1) * 32 + l31;
-    xbase[n] = prow * P::Q * P::PC + pcol * P::Q;
+#pragma unroll
+    for (int d = 0; d < C::ND; d++)
+      bbase[n][d] = lds0 + (unsigned)(prow * P::Q * P::PC + pcol * P::Q + half * C::delta(d)) * 4u;
   }
-  const int wbase = wm * MT * 32 + l31;
+  static_assert(C::STAGE * 4 <= 65536, "operand offsets of one buffer fit the 16-bit immediate");
+  static_assert(kAhead * (MT + NT) <= 15, "lgkmcnt counts to 15");
 
-  stage_chunk(0, 0);
+  stager(0, 0).issue_all();
   __syncthreads();  // (also waits for the DMA: vmcnt(0))
 
   for (int chunk = 0; chunk < nchunk; chunk++) {
-    const int buf = chunk & 1;
     // the other buffer's last readers finished before the barrier that ended the
     // previous iteration; the DMA has the whole MFMA block to land
-    if (chunk + 1 < nchunk) stage_chunk(chunk + 1, buf ^ 1);
-    const float *xs = lds + buf * C::STAGE;
-    const float *ws = xs + C::XSZ;
-    // operands of k-pair kp+1 are read from LDS before the MFMAs of k-pair kp are
-    // issued (two named register sets, the loop is unrolled in pairs), so the LDS
-    // latency hides behind 64*MT*NT cycles of matrix work instead of stalling the
-    // wave in front of every group
-    float a0[MT], b0[NT], a1[MT], b1[NT];
-    // the two lane halves work on reduction entries 2kp and 2kp+1
-#define PCONV_READ_PAIR(KP, A, B)                                                            \
-  {                                                                                          \
-    constexpr int KS2 = KS * KS;                                                             \
-    const int ka = 2 * (KP), kb = 2 * (KP) + 1;                                              \
-    const int offa = (ka / KS2) * P::PR * P::PC + ((ka / KS) % KS) * P::PC + (ka % KS);      \
-    const int offb = (kb / KS2) * P::PR * P::PC + ((kb / KS) % KS) * P::PC + (kb % KS);      \
-    const int xoff = half ? offb : offa;                                                     \
-    const int woff = (2 * (KP) + half) * C::BM + wbase;                                      \
-    _Pragma("unroll") for (int m = 0; m < MT; m++) A[m] = ws[woff + m * 32];                 \
-    _Pragma("unroll") for (int n = 0; n < NT; n++) {                                         \
-      B[n] = xs[xbase[n] + xoff];                                                            \
-      if (SQ) B[n] = B[n] * B[n];                                                            \
-    }                                                                                        \
-  }
-#define PCONV_MFMA_BLOCK(A, B)                                                               \
-  {                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    _Pragma("unroll") for (int m = 0; m < MT; m++) _Pragma("unroll") for (int n = 0; n < NT; n++) \
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m], B[n], acc[m][n], 0, 0, 0);    \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-  }
-    static_assert(C::KK % 4 == 0, "k-pairs are processed two at a time");
-    PCONV_READ_PAIR(0, a0, b0)
+    stager(chunk + 1, (chunk & 1) ^ 1).issue_all();
+    float a[kAhead + 1][MT], b[kAhead + 1][NT];
+    conv_chunk_prologue<C, 0>(a, b, abase, bbase);
+    conv_chunk_step<C, SQ, 0>(acc, a, b, abase, bbase);
+    // on to the other buffer
+    const unsigned flip = (chunk & 1) ? (unsigned)(-C::STAGE * 4) : (unsigned)(C::STAGE * 4);
+    abase += flip;
 #pragma unroll
-    for (int kq = 0; kq < C::KK / 4; kq++) {
-      PCONV_READ_PAIR(2 * kq + 1, a1, b1)
-      PCONV_MFMA_BLOCK(a0, b0)
-      if (2 * kq + 2 < C::KK / 2) PCONV_READ_PAIR(2 * kq + 2, a0, b0)
-      PCONV_MFMA_BLOCK(a1, b1)
-    }
-#undef PCONV_READ_PAIR
-#undef PCONV_MFMA_BLOCK
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int d = 0; d < C::ND; d++) bbase[n][d] += flip;
+#ifndef PCONV_ABL_NOBAR
     __syncthreads();
+#endif
   }
 
+#ifdef PCONV_ABL_NOEPI
+  if (cin == -12345)
+#endif
   conv_epilogue<MT, NT, WN>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half);
 }
 
