@@ -271,8 +271,8 @@ __device__ __forceinline__ void stage_weights(float *wl, const float *__restrict
 // per wave, so what matters is how many waves are resident (<= 64 registers: 8 per SIMD)
 // and how few dependent hops a position takes: no integer division anywhere (3-D grid,
 // precomputed records), halo entries written from 16-byte records (2 hops instead of 4).
-template <int CIN, int ITER, int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER <= 20 ? 8 : (ITER <= 40 ? 4 : 2))) void ee_step_kernel(
+template <int CIN, int ITER, int BLOCK, int PJ>
+__global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (ITER * PJ <= 40 ? (PJ > 1 ? 6 : 4) : 2))) void ee_step_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const uint32_t *__restrict__ tapoff, const float *__restrict__ bias, const float *__restrict__ slope,
     const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum) {
@@ -303,9 +303,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER <= 20 ? 8 : (ITER <=
     for (int i = wave; i < ITER; i += kWaves)
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)(slab + i * kWave + lane), (lds_ptr_t *)(lw + i * kWave), 16, 0, 0);
   }
-  unsigned off[ITER];  // byte offsets: unsigned 32-bit, so the gathers are "scalar base + lane offset" loads
+  // byte offsets of a lane's ITER taps inside a window: unsigned 32-bit, so the gathers are "scalar
+  // base + lane offset" loads.  One position at a time they live in registers; with PJ > 1 the
+  // registers go to the second window and the table sits in LDS (read once per PJ positions)
+  unsigned off[PJ > 1 ? 1 : ITER];
+  __shared__ unsigned toff[PJ > 1 ? SLOTS : 1];
+  if (PJ > 1) {
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    for (int i = wave; i < ITER; i += kWaves)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(tapoff + i * kWave + lane), (lds_ptr_t *)(toff + i * kWave), 4, 0, 0);
+  } else {
 #pragma unroll
-  for (int it = 0; it < ITER; it++) off[it] = tapoff[it * kWave + lane];
+    for (int it = 0; it < ITER; it++) off[it] = tapoff[it * kWave + lane];
+  }
   const int pout0 = tc * GO;
   const int bidx = set * cout + pout0;
   const float b0 = bias[bidx], b1 = bias[bidx + 1], b2 = bias[bidx + 2];
@@ -335,73 +346,130 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER <= 20 ? 8 : (ITER <=
     p.rev = plist[4 * i + 3];
     return p;
   };
-  EePos rec = load_pos(e);
+  // PJ positions (e, e + stride, ...) go through the loop body together: their gathers are in
+  // flight at the same time, ONE pass over the LDS slab feeds all their fmaf chains (the slab reads
+  // were as many LDS cycles as the fmafs were VALU cycles), and a wave's chain of dependent round
+  // trips is PJ times shorter.  Per position the operations and their order are unchanged.
+  EePos rec[PJ];
+#pragma unroll
+  for (int j = 0; j < PJ; j++) rec[j] = load_pos(e + j * stride < cnt ? e + j * stride : e);
 #pragma unroll 1
   for (;;) {
-    const int en = e + stride;
-    const EePos nxt = load_pos(en < cnt ? en : e);  // requested now, used by the next iteration
-    const float *xin = ximg + (size_t)rec.pix * CIN;     // window origin (row-2, col-2) in padded coordinates
-    const size_t oflat = (size_t)(pad_out ? rec.pix + 2 * win + 2 : rec.hw) * cout + pout0;
-    float xv[ITER];
+    const int en = e + PJ * stride;
+    EePos nxt[PJ];  // requested now, used by the next iteration
+#pragma unroll
+    for (int j = 0; j < PJ; j++) nxt[j] = load_pos(en + j * stride < cnt ? en + j * stride : e);
+    float xv[PJ][ITER];
+    size_t oflat[PJ];
+    float r0[PJ], r1[PJ], r2[PJ];  // issued with the gathers: one memory round trip per position
+    const float *xin[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      xin[j] = ximg + (size_t)rec[j].pix * CIN;  // window origin (row-2, col-2) in padded coordinates
+      oflat[j] = (size_t)(pad_out ? rec[j].pix + 2 * win + 2 : rec[j].hw) * cout + pout0;
+    }
+    int tl = lane;  // (opaque: the table reads below must not be hoisted out of the position loop into registers)
+    asm volatile("" : "+v"(tl));
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
       // (opaque to the optimiser: a zero-extension hoisted out of the loop would
       // turn every gather into a 64-bit VALU add + a 2-register address)
-      unsigned o = off[it];
+      unsigned o = PJ > 1 ? toff[tl + it * kWave] : off[PJ > 1 ? 0 : it];
       asm volatile("" : "+v"(o));
-      xv[it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
-    }
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;  // issued with the gathers: one memory round trip per position
-    if (rimg) {
-      r0 = rimg[oflat];
-      r1 = rimg[oflat + 1];
-      r2 = rimg[oflat + 2];
-    }
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      const float4 wv = lw[lane + it * kWave];
-      // (the padding float kept live: a 16-byte ds_read_b128 takes 4 LDS cycles, the
-      // 12-byte ds_read_b96 the compiler would otherwise pick takes 8)
-      asm volatile("" ::"v"(wv.w));
-      a0 = fmaf(xv[it], wv.x, a0);
-      a1 = fmaf(xv[it], wv.y, a1);
-      a2 = fmaf(xv[it], wv.z, a2);
+      for (int j = 0; j < PJ; j++)
+        xv[j][it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin[j]) + o);
     }
-    // one packed butterfly; the row of 16 lanes a lane sits in decides which output it
-    // finishes (rows 0 / 2 / 1,3 -> outputs 0 / 1 / 2), and the epilogue is spread the same way
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      r0[j] = r1[j] = r2[j] = 0.f;
+      if (rimg) {
+        r0[j] = rimg[oflat[j]];
+        r1[j] = rimg[oflat[j] + 1];
+        r2[j] = rimg[oflat[j] + 2];
+      }
+    }
+    float a0[PJ], a1[PJ], a2[PJ];
+    if constexpr (PJ == 2) {
+      // the two positions' chains as packed fp32 FMAs (v_pk_fma_f32: two IEEE fmas per instruction,
+      // the same bits as two v_fma_f32)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const float4 wv = lw[lane + it * kWave];
+        asm volatile("" ::"v"(wv.w));  // (see below)
+        const f2 xx = {xv[0][it], xv[1][it]};
+        p0 = __builtin_elementwise_fma(xx, (f2){wv.x, wv.x}, p0);
+        p1 = __builtin_elementwise_fma(xx, (f2){wv.y, wv.y}, p1);
+        p2 = __builtin_elementwise_fma(xx, (f2){wv.z, wv.z}, p2);
+        if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      a0[0] = p0.x, a0[1] = p0.y, a1[0] = p1.x, a1[1] = p1.y, a2[0] = p2.x, a2[1] = p2.y;
+    } else {
+#pragma unroll
+      for (int j = 0; j < PJ; j++) a0[j] = a1[j] = a2[j] = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const float4 wv = lw[lane + it * kWave];
+        // (the padding float kept live: a 16-byte ds_read_b128 takes 4 LDS cycles, the
+        // 12-byte ds_read_b96 the compiler would otherwise pick takes 8)
+        asm volatile("" ::"v"(wv.w));
+#pragma unroll
+        for (int j = 0; j < PJ; j++) {
+          a0[j] = fmaf(xv[j][it], wv.x, a0[j]);
+          a1[j] = fmaf(xv[j][it], wv.y, a1[j]);
+          a2[j] = fmaf(xv[j][it], wv.z, a2[j]);
+        }
+      }
+    }
+    // one packed butterfly per position; the row of 16 lanes a lane sits in decides which output
+    // it finishes (rows 0 / 2 / 1,3 -> outputs 0 / 1 / 2), and the epilogue is spread the same way
     const int row = lane >> 4;
     const int o = row == 0 ? 0 : (row == 2 ? 1 : 2);
-    float v = butterfly3(a0, a1, a2) + (o == 0 ? b0 : (o == 1 ? b1 : b2));
-    if (slope) {
-      const float sl = o == 0 ? s0 : (o == 1 ? s1 : s2);
-      v = v < 0 ? v * sl : v;
-    }
-    if (rimg) v = v + (o == 0 ? r0 : (o == 1 ? r1 : r2));
     const bool writer = (lane & 15) == 0 && row != 3;  // one lane per output
-    if (writer) yimg[oflat + o] = v;
-    if (pad_out) {
-      if (rec.wrap && writer) yimg[oflat + (size_t)rec.wrap * cout + o] = v;  // circular wrap copy
-      const int nrev = rec.rev & 15;
-      if (nrev && row != 3) {
-        // this value feeds halo rows of the neighbouring tiles: the 16 lanes of a row share
-        // the entries interpolated from it
-        const EeHalo *hr = g.halo + (rec.rev >> 4);
-        const int ch = pout0 + o;
-        for (int k = lane & 15; k < nrev; k += 16) {
-          const EeHalo q = hr[k];
-          const float other = (q.info & (1 << 29)) ? v : (q.other >= 0 ? yimg[(size_t)q.other * cout + ch] : 0.f);
-          const float a = (q.info & (1 << 30)) ? other : v, b = (q.info & (1 << 30)) ? v : other;
-          const float hv = a * q.t + b * (1 - q.t);
-          float *dst = yimg + (size_t)q.dst * cout + ch;
-          *dst = hv;
-          const int wd = q.info & 0xffff;
-          if (wd) dst[(size_t)wd * cout] = hv;  // circular wrap of the first columns
+    float vsum[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      vsum[j] = butterfly3(a0[j], a1[j], a2[j]);
+      // (opaque: otherwise the whole chain of a position that may not exist -- gathers, slab reads,
+      // fmafs -- is sunk into the branch that stores it, and the positions run one after the other)
+      asm volatile("" : "+v"(vsum[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      if (j > 0 && e + j * stride >= cnt) break;  // (uniform) no such position: its lanes computed a copy of e
+      float v = vsum[j] + (o == 0 ? b0 : (o == 1 ? b1 : b2));
+      if (slope) {
+        const float sl = o == 0 ? s0 : (o == 1 ? s1 : s2);
+        v = v < 0 ? v * sl : v;
+      }
+      if (rimg) v = v + (o == 0 ? r0[j] : (o == 1 ? r1[j] : r2[j]));
+      if (writer) yimg[oflat[j] + o] = v;
+      if (pad_out) {
+        if (rec[j].wrap && writer) yimg[oflat[j] + (size_t)rec[j].wrap * cout + o] = v;  // circular wrap copy
+        const int nrev = rec[j].rev & 15;
+        if (nrev && row != 3) {
+          // this value feeds halo rows of the neighbouring tiles: the 16 lanes of a row share
+          // the entries interpolated from it
+          const EeHalo *hr = g.halo + (rec[j].rev >> 4);
+          const int ch = pout0 + o;
+          for (int k = lane & 15; k < nrev; k += 16) {
+            const EeHalo q = hr[k];
+            const float other = (q.info & (1 << 29)) ? v : (q.other >= 0 ? yimg[(size_t)q.other * cout + ch] : 0.f);
+            const float a = (q.info & (1 << 30)) ? other : v, b = (q.info & (1 << 30)) ? v : other;
+            const float hv = a * q.t + b * (1 - q.t);
+            float *dst = yimg + (size_t)q.dst * cout + ch;
+            *dst = hv;
+            const int wd = q.info & 0xffff;
+            if (wd) dst[(size_t)wd * cout] = hv;  // circular wrap of the first columns
+          }
         }
       }
     }
     if (en >= cnt) break;
-    rec = nxt;
+#pragma unroll
+    for (int j = 0; j < PJ; j++) rec[j] = nxt[j];
     e = en;
   }
 }
@@ -802,15 +870,23 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   // 1024-thread workgroups are slower at every batch size
   static const int ppw_env = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : 0;
   const int ppw = ppw_env > 0 ? ppw_env : (g->nimg <= 1 ? 2 : kPosPerWave);
+  // PCONV_EE_JOINT: positions a wave takes through the loop body together (1 or 2)
+  static const int joint = getenv("PCONV_EE_JOINT") ? atoi(getenv("PCONV_EE_JOINT")) : 2;
   const int waves = block / kWave;
   int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;
   const uint32_t *tap = cin == g->ngroup ? g->tap_in : g->tap_hid;
   const dim3 grid((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));
   PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images for one launch");
-#define EE_LAUNCH_B(CIN, ITER, BLK)                                                                          \
-  hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, BLK>), grid, dim3(BLK), 0, as_stream(stream), *g, x,         \
+#define EE_LAUNCH_J(CIN, ITER, BLK, PJ)                                                                      \
+  hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, BLK, PJ>), grid, dim3(BLK), 0, as_stream(stream), *g, x,     \
                      shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum)
+#define EE_LAUNCH_B(CIN, ITER, BLK)                          \
+  if (joint == 2 && ITER <= 20 && ppw >= 2) {                \
+    EE_LAUNCH_J(CIN, ITER, BLK, (ITER <= 20 ? 2 : 1));       \
+  } else {                                                   \
+    EE_LAUNCH_J(CIN, ITER, BLK, 1);                          \
+  }
 #define EE_LAUNCH(CIN, ITER)              \
   if (block == 1024) {                    \
     EE_LAUNCH_B(CIN, ITER, 1024);         \
@@ -837,6 +913,7 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   }
 #undef EE_LAUNCH
 #undef EE_LAUNCH_B
+#undef EE_LAUNCH_J
   PCONV_LAUNCH_CHECK("ee_conv");
   return PCONV_OK;
 }
