@@ -14,6 +14,9 @@ python bench.py > $O/bench_n1.json 2> $O/bench_n1.err || { tail -30 $O/bench_n1.
 cat $O/bench_n1.json
 python bench.py --mode analysis --steps 5 --warmup 2 > $O/analysis_1024x2048.json 2> $O/analysis.err || { tail -30 $O/analysis.err; exit 1; }
 cut -c1-400 $O/analysis_1024x2048.json
+PCONV_BENCH_TABLE=1 python bench.py --mode analysis --height 2048 --width 4096 --steps 3 --warmup 1 > $O/analysis_4096x2048.json 2>> $O/analysis.err || { tail -30 $O/analysis.err; exit 1; }
+cut -c1-300 $O/analysis_4096x2048.json
+for n in 1 2 4; do python bench.py --frames-per-gpu $n --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | cut -c1-140; done | tee $O/bench_frames_1_2_4.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench /tmp/prof_an
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 1 --warmup 0 --prime 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err || tail -5 $O/bench_under_rocprof.err
