@@ -909,7 +909,8 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
   int rc;
 #define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, vin, vout, ep, s
   // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):
-  //   cout > 96 : 192 couts x (2 rows x 64 px), 8 waves of 96 x 32 (4 waves of 96 x 64: -2 %)
+  //   cout > 96 : 192 couts x (2 rows x 64 px), 8 waves of 96 x 32: 135.8 TFLOP/s (4 waves of 96 x 64 px
+  //               = 3 x 2 accumulator tiles each: 128.3; 6 such waves on 3 rows x 64 px: 97)
   //   cout > 32 :  96 couts x (4 rows x 64 px), 8 waves of 96 x 32
   //   else      :  32 couts x (2 rows x 64 px), 4 waves of 32 x 32
 #define BY_TILE(KS, S, KC)                                         \
