@@ -275,7 +275,8 @@ template <int CIN, int ITER, int BLOCK, int PJ>
 __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (ITER * PJ <= 40 ? (PJ > 1 ? 6 : 4) : 2))) void ee_step_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const uint32_t *__restrict__ tapoff, const float *__restrict__ bias, const float *__restrict__ slope,
-    const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum) {
+    const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum,
+    int contiguous) {
   constexpr int kWaves = BLOCK / kWave;
   constexpr int SLOTS = ITER * kWave;
   static_assert(SLOTS == slab_slots(CIN), "ITER must cover the padded reduction length");
@@ -288,7 +289,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
   const_i32_t *pstart = (const_i32_t *)g.plane_start;
   const int lo = pstart[plane];
   const int cnt = pstart[plane + 1] - lo;
-  if (part * kWaves >= cnt) return;  // uniform for the workgroup
+  // A workgroup takes a CONTIGUOUS share of the plane's position list (neighbours on the
+  // anti-diagonal: their 5 x 5 windows overlap, 16 of 25 taps between direct neighbours, so what
+  // one wave gathered the next finds in the CU's L1) -- the kernel is bound by the bytes its
+  // gathers pull out of L2.  contiguous = 0: the interleaved assignment (position e of a wave,
+  // e + waves*parts the next one).
+  const int share = contiguous ? (cnt + split - 1) / split : cnt;
+  const int first = contiguous ? part * share : part * kWaves;
+  const int last = contiguous ? (first + share < cnt ? first + share : cnt) : cnt;
+  if (first >= cnt) return;  // uniform for the workgroup
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int tc = psum - plane;
@@ -332,9 +341,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
   float *yimg = y + (size_t)pn * out_img;
   const float *rimg = residual ? residual + (size_t)pn * out_img : nullptr;
   __syncthreads();  // (waits for the DMA: vmcnt(0))
-  int e = part * kWaves + wave;
-  if (e >= cnt) return;
-  const int stride = split * kWaves;
+  int e = first + wave;
+  if (e >= last) return;
+  const int stride = contiguous ? kWaves : split * kWaves;
   // read-only table, wave-uniform index: through the constant address space these are
   // scalar loads (s_load_dwordx4), not a vector load + readfirstlane
   const_i32_t *plist = (const_i32_t *)(g.pos + lo);
@@ -352,13 +361,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
   // trips is PJ times shorter.  Per position the operations and their order are unchanged.
   EePos rec[PJ];
 #pragma unroll
-  for (int j = 0; j < PJ; j++) rec[j] = load_pos(e + j * stride < cnt ? e + j * stride : e);
+  for (int j = 0; j < PJ; j++) rec[j] = load_pos(e + j * stride < last ? e + j * stride : e);
 #pragma unroll 1
   for (;;) {
     const int en = e + PJ * stride;
     EePos nxt[PJ];  // requested now, used by the next iteration
 #pragma unroll
-    for (int j = 0; j < PJ; j++) nxt[j] = load_pos(en + j * stride < cnt ? en + j * stride : e);
+    for (int j = 0; j < PJ; j++) nxt[j] = load_pos(en + j * stride < last ? en + j * stride : e);
     float xv[PJ][ITER];
     size_t oflat[PJ];
     float r0[PJ], r1[PJ], r2[PJ];  // issued with the gathers: one memory round trip per position
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
     }
 #pragma unroll
     for (int j = 0; j < PJ; j++) {
-      if (j > 0 && e + j * stride >= cnt) break;  // (uniform) no such position: its lanes computed a copy of e
+      if (j > 0 && e + j * stride >= last) break;  // (uniform) no such position: its lanes computed a copy of e
       float v = vsum[j] + (o == 0 ? b0 : (o == 1 ? b1 : b2));
       if (slope) {
         const float sl = o == 0 ? s0 : (o == 1 ? s1 : s2);
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
         }
       }
     }
-    if (en >= cnt) break;
+    if (en >= last) break;
 #pragma unroll
     for (int j = 0; j < PJ; j++) rec[j] = nxt[j];
     e = en;
@@ -865,13 +874,16 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   // slab serves several positions.  PCONV_EE_BLOCK (threads per workgroup: 256 / 512 / 1024)
   // and PCONV_EE_PPW (positions a wave walks) are tuning knobs.
   static const int block = getenv("PCONV_EE_BLOCK") ? atoi(getenv("PCONV_EE_BLOCK")) : kConvBlock;
-  // measured (MI355X, 4096x2048, decode of 1 / 2 / 4 / 8 frames in two groups): 4 positions
-  // per wave 106 / 122 / 163 / 230 ms, 2 positions 99 / 117 / 159 / 257 ms; 512- and
-  // 1024-thread workgroups are slower at every batch size
+  // measured (MI355X, 4096x2048, decode of 1 / 2 / 4 / 8 frames in two groups, contiguous shares, two
+  // positions per loop body): 2 positions per wave 93 / 109 / - / - ms, 4: 96 / 110 / 150 / 222,
+  // 8: 116 / 126 / 140 / 211, 16: - / 137 / 164 / 213; 512- and 1024-thread workgroups are slower
+  // at every batch size
   static const int ppw_env = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : 0;
-  const int ppw = ppw_env > 0 ? ppw_env : (g->nimg <= 1 ? 2 : kPosPerWave);
+  const int ppw = ppw_env > 0 ? ppw_env : (g->nimg <= 1 ? 2 : 2 * kPosPerWave);
   // PCONV_EE_JOINT: positions a wave takes through the loop body together (1 or 2)
   static const int joint = getenv("PCONV_EE_JOINT") ? atoi(getenv("PCONV_EE_JOINT")) : 2;
+  // PCONV_EE_CONTIG: contiguous (1) or interleaved (0) shares of a plane per workgroup
+  static const int contig = getenv("PCONV_EE_CONTIG") ? atoi(getenv("PCONV_EE_CONTIG")) : 1;
   const int waves = block / kWave;
   int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;
@@ -880,7 +892,7 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images for one launch");
 #define EE_LAUNCH_J(CIN, ITER, BLK, PJ)                                                                      \
   hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, BLK, PJ>), grid, dim3(BLK), 0, as_stream(stream), *g, x,     \
-                     shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum)
+                     shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum, contig)
 #define EE_LAUNCH_B(CIN, ITER, BLK)                          \
   if (joint == 2 && ITER <= 20 && ppw >= 2) {                \
     EE_LAUNCH_J(CIN, ITER, BLK, (ITER <= 20 ? 2 : 1));       \
