@@ -172,6 +172,24 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
   }
 #pragma unroll
   for (int m = 0; m < MT; m++) {
+    // the residual values of the whole 32-cout tile are requested first, in one batch: one by one
+    // in front of their use (the compiler cannot move a load above the previous store of `out`)
+    // every one of the 16 x NT round trips was exposed -- 8 % of the kernel on the residual layers
+    float rv[16][NT];
+    if (resp) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int seg = wn * NT + n;
+          const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+          rv[r][n] = (co < cout && orow < ho && ocol < wo)
+                         ? resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol]
+                         : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -196,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
             v = 1.f / (1.f + expf(-v));
           }
           if (gatep) v = gatep[(size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + ocol] * v;
-          if (resp) v = resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol] + v;
+          if (resp) v = rv[r][n] + v;
           if (ocol >= trim_at) v = 0.f;
           outp[oi] = v;
         }
