@@ -774,11 +774,17 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
   //     scatter kernel waits in memory for the symbols, its table kernel announces the rows
   //     there -- and a second thread only polls, decodes and publishes: no launch and no
   //     stream synchronisation on the critical path of a step;
-  //   PCONV_ENGINE_CHAIN=host: the host launches a step after it has decoded the previous
-  //     one (kept as the checker of the queued chain: tests/test_gpu_engine.py).
+  //   host-driven chain: the host launches a step after it has decoded the previous one (also the
+  //     checker of the queued chain: tests/test_gpu_engine.py).
+  //   Which one: the queued chain moves the CDF rows and the symbols by zero-copy accesses of the kernels
+  //     themselves, the host-driven one by bulk copies; measured (MI355X, 4096x2048, two groups) queued /
+  //     host-driven: 94 / 103 ms for one frame, 110 / 113 for two, 141 / 137 for four, 212 / 197 for eight
+  //     (four frames per group: 276 KB of rows per step).  PCONV_ENGINE_CHAIN=queued|host overrides.
   const char *chain_env = getenv("PCONV_ENGINE_CHAIN");
-  const bool chained = !(chain_env && chain_env[0] == 'h');
   const int ng = (int)e->groups.size();
+  int largest = 0;
+  for (const Group &g : e->groups) largest = std::max(largest, g.nimg);
+  const bool chained = chain_env ? chain_env[0] != 'h' : largest < 4;
   std::vector<int> rcs(ng, PCONV_OK);
   std::vector<std::string> errors(ng);
   std::vector<double> waits(ng, 0.0), coders(ng, 0.0);

@@ -136,14 +136,17 @@ def test_queued_chain_equals_host_driven_chain(hip_backend, monkeypatch):
     sym = eng.symbols(x)
     for n in (1, 3):
         e = eng._engine("dec", sym.shape[2], sym.shape[3], n)
+        monkeypatch.setenv("PCONV_ENGINE_CHAIN", "queued")   # (the default picks by frames per group)
         queued = e.decode(streams[:n])
         monkeypatch.setenv("PCONV_ENGINE_CHAIN", "host")
         host = e.decode(streams[:n])
-        monkeypatch.delenv("PCONV_ENGINE_CHAIN")
+        monkeypatch.setenv("PCONV_ENGINE_CHAIN", "queued")
         assert torch.equal(queued, host)
         assert torch.equal(queued, sym[:16 * n])
         again = e.decode(streams[:n])   # flags and counters are back in their initial state
         assert torch.equal(again, queued)
+        monkeypatch.delenv("PCONV_ENGINE_CHAIN")
+        assert torch.equal(e.decode(streams[:n]), queued)
 
 
 def test_pipelined_decode_equals_plain_decode(hip_backend, monkeypatch):
