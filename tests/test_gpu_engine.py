@@ -149,6 +149,19 @@ def test_queued_chain_equals_host_driven_chain(hip_backend, monkeypatch):
         assert torch.equal(e.decode(streams[:n]), queued)
 
 
+def test_eight_frames_take_the_host_driven_chain_by_default(hip_backend):
+    """groups of four or more frames decode through the host-driven chain (faster there); the
+    choice is by frames per group, the result is the same"""
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = _codec()
+    eng = CodecEngine(56, 0, enc, dec)
+    x = _frames(8, 256, 512, seed=19)
+    streams = eng.encode(x)
+    sym = eng.symbols(x)
+    e = eng._engine("dec", sym.shape[2], sym.shape[3], 8)
+    assert torch.equal(e.decode(streams), sym)
+
+
 def test_pipelined_decode_equals_plain_decode(hip_backend, monkeypatch):
     """CodecEngine.decode with DECODE_CHUNK: the entropy decoder of chunk k+1 runs beside the
     synthesis of chunk k (second stream, host thread, two engines) -- same images"""
