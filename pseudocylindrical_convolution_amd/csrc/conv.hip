@@ -33,6 +33,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTileCols = 64;
+#ifndef PCONV_KC1
+#define PCONV_KC1 16  // input channels per LDS stage of the 1x1 layers
+#endif
 
 template <int ROWS, int KS, int S>
 struct Patch {
@@ -175,8 +178,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
     // the residual values of the whole 32-cout tile are requested first, in one batch: one by one
     // in front of their use (the compiler cannot move a load above the previous store of `out`)
     // every one of the 16 x NT round trips was exposed -- 8 % of the kernel on the residual layers
-    float rv[16][NT];
-    if (resp) {
+    float rv[16][NT], q1[16][NT];  // q1: the GDN's own input, or the attention gate (never both)
+    const bool gdn = act == 2 || act == 3;
+    auto batch = [&](float (&dst)[16][NT], const float *src, const ConvView &v) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -184,12 +188,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
         for (int n = 0; n < NT; n++) {
           const int seg = wn * NT + n;
           const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
-          rv[r][n] = (co < cout && orow < ho && ocol < wo)
-                         ? resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol]
-                         : 0.f;
+          dst[r][n] = (co < cout && orow < ho && ocol < wo) ? src[(size_t)co * v.cs + (size_t)orow * v.rs + ocol] : 1.f;
         }
       }
-    }
+    };
+    if (resp) batch(rv, resp, ep.vres);
+    if (gdn) batch(q1, inp, vin);  // (likewise everything else the way out reads)
+    if (gatep) batch(q1, gatep, ep.vgate);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -205,15 +210,15 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
           float v = acc[m][n][r] + bco;
           if (act == 1) {
             if (v < 0) v = v * sl;
-          } else if (act == 2 || act == 3) {
+          } else if (gdn) {
             // 1x1, stride 1: input and output share their geometry
-            const float xv = inp[(size_t)co * vin.cs + (size_t)orow * vin.rs + ocol];
+            const float xv = q1[r][n];
             const float nrm = sqrtf(v);
             v = act == 2 ? xv / nrm : xv * nrm;
           } else if (act == 4) {
             v = 1.f / (1.f + expf(-v));
           }
-          if (gatep) v = gatep[(size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + ocol] * v;
+          if (gatep) v = q1[r][n] * v;
           if (resp) v = rv[r][n] + v;
           if (ocol >= trim_at) v = 0.f;
           outp[oi] = v;
@@ -542,8 +547,8 @@ __device__ __forceinline__ float4 load4_base_off(global_bytes *base, unsigned of
 template <int WM, bool SQ>
 __global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int kpad, int h, int w,
-    int cout, int cout_pad, int tiles_r, int tiles_c, int cblocks, int passes, ConvView vin, ConvView vout,
-    ConvEpilogue ep) {
+    int cout, int cout_pad, int tiles_r, int tiles_c, int cblocks, int passes, int stagger, ConvView vin,
+    ConvView vout, ConvEpilogue ep) {
   constexpr int kThreads = 512, MT = 3, NT = 4, BM = 96 * WM, WP = 8 / WM, ROWS = WP / 2, D = 5;
   constexpr int kCols = 256;
   extern __shared__ float lds[];  // ws[kpad][BM]
@@ -584,6 +589,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
   // this lane's 4 columns (the last 4 of the row for lanes past the edge)
   const int col = gc0 + 4 * l31 < w - 4 ? gc0 + 4 * l31 : w - 4;
   const bool group_dead = gc0 >= dead_at;
+  // Waves w and w + 4 share a SIMD.  Started together they stay together: both in the matrix loop
+  // (taking turns on the one matrix pipe), then both in the way out (pipe idle, 3 x 16-byte accesses
+  // per 4 outputs each).  Holding the second wave back by about one matrix loop puts one of them on
+  // the pipe while the other moves data.  (The pair that shares its B operands, waves 2q and 2q + 1,
+  // sits in the same half and keeps its phase.)
+  if (wave >= 4)
+    for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(127);
 #pragma unroll 1
   for (int pass = 0; pass < passes; pass++) {
     const int orow = (trx * passes + pass) * ROWS + (wq >> 1);
@@ -776,8 +788,11 @@ int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin
       raised.fetch_or(bit, std::memory_order_release);
     }
   }
+  // second wave of every SIMD held back (units of 127 x 64 cycles); PCONV_CONV1X1_STAGGER: experiment knob
+  static const int stagger_env = getenv("PCONV_CONV1X1_STAGGER") ? atoi(getenv("PCONV_CONV1X1_STAGGER")) : -1;
+  const int stagger = stagger_env >= 0 ? stagger_env : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, in, wp, out, kpad, h, w, cout, cout_pad,
-                     tiles_r, tiles_c, cblocks, passes, vin, vout, ep);
+                     tiles_r, tiles_c, cblocks, passes, stagger, vin, vout, ep);
   return PCONV_OK;
 }
 
@@ -793,10 +808,15 @@ inline bool use_resident_1x1(int cin, int cout, int tn, int h, int w) {
   const int bm = cout > 96 ? 192 : 96;
   if (!(cin >= 32 && cin % 16 == 0 && cout > 32 && (size_t)kpad * bm * sizeof(float) <= 150 * 1024)) return false;
   if (w < 4) return false;
-  if (env && env[0] == 'r') return true;  // forced (tests)
-  // measured (MI355X, 4096x2048 frame): 96->192, 192->192 and the GDN gain 10-25 % at the
-  // quarter / half scales; the 96-cout layers (one cout block, 1024-pixel tiles) lose 10 %
-  return cout > 96 && (long long)tn * h * w >= 256LL * 1024;
+  if (env && env[0] == 'r') return true;  // forced (tests, A/B measurements)
+  // Measured (MI355X, layers of a 4096x2048 frame).  Against the tiled kernel of round 2's first
+  // half this form gained 10-25 % on 96->192, 192->192 and the GDN.  Since the tiled kernel reads
+  // its LDS operands with counted waits and requests what its way out reads in batches, it is the
+  // faster one everywhere: 96->192 + residual 0.36 vs 0.41 ms, 192->192 0.50 vs 0.56, 192->768
+  // 1.51 vs 1.59, GDN at 2048 columns 2.14 vs 2.63 ms.  The resident form stays as the measured
+  // alternative (PCONV_CONV1X1=resident).
+  (void)tn, (void)h;
+  return false;
 }
 
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded
@@ -875,7 +895,7 @@ inline bool view_ok(const ConvView &v, int c, int h, int w) {
 extern "C" int pconv_conv_packed_size(int cout, int cin, int k, int *cout_pad, int *red_pad) {
   // cout padded to the widest workgroup tile, reduction to whole chunks
   const int cp = round_up(cout, cout > 96 ? 192 : (cout > 32 ? 96 : 32));
-  const int kc = (k == 1) ? 16 : 4;
+  const int kc = (k == 1) ? PCONV_KC1 : 4;
   const int rp = round_up(cin, kc) * k * k;
   if (cout_pad) *cout_pad = cp;
   if (red_pad) *red_pad = rp;
@@ -948,9 +968,9 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
     else
       rc = launch_conv1x1<1, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
   } else if (k == 1 && stride == 1) {
-    BY_TILE(1, 1, 16)
+    BY_TILE(1, 1, PCONV_KC1)
   } else {
-    BY_TILE(1, 2, 16)
+    BY_TILE(1, 2, PCONV_KC1)
   }
 #undef BY_TILE
 #undef ARGS
@@ -985,11 +1005,11 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
   else if (use_resident_1x1(ch, ch, tn, h, w))
     rc = launch_conv1x1<1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
   else if (ch > 96)
-    rc = launch_conv<3, 1, 2, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
+    rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)
-    rc = launch_conv<3, 1, 1, 8, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
+    rc = launch_conv<3, 1, 1, 8, 1, 1, PCONV_KC1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else
-    rc = launch_conv<1, 1, 1, 4, 1, 1, 16, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
+    rc = launch_conv<1, 1, 1, 4, 1, 1, PCONV_KC1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   if (rc != PCONV_OK) return rc;
   PCONV_LAUNCH_CHECK("gdn");
   return PCONV_OK;
