@@ -1034,14 +1034,14 @@ _VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stac
 
 def conv_kernel_name(cout, k, stride, squared=False, cin=0, pixels=0):
     """the kernel instantiation pconv_conv2d / pconv_gdn pick for a layer (csrc/conv.hip), as
-    rocprofv3 prints it: the weight-resident conv1x1_rb_kernel<WM, SQ> for 1x1 stride-1 layers
-    whose slab fits LDS and that fill the chip, else conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>"""
+    rocprofv3 prints it: conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>, or -- only when
+    PCONV_CONV1X1=resident asks for it -- the weight-resident conv1x1_rb_kernel<WM, SQ> for 1x1
+    stride-1 layers whose slab fits LDS (use_resident_1x1 in conv.hip)"""
     import os
     sq = "true" if squared else "false"
     mode = os.environ.get("PCONV_CONV1X1", "auto")[0]
-    if k == 1 and stride == 1 and cin >= 32 and cin % 16 == 0 and cout > 32 and mode != "t" and \
-            (cin + 15) // 16 * 16 * (192 if cout > 96 else 96) * 4 <= 150 * 1024 and \
-            (mode == "r" or (cout > 96 and pixels >= 256 * 1024)):
+    if k == 1 and stride == 1 and cin >= 32 and cin % 16 == 0 and cout > 32 and mode == "r" and \
+            (cin + 15) // 16 * 16 * (192 if cout > 96 else 96) * 4 <= 150 * 1024:
         return "conv1x1_rb_kernel<%d, %s>" % (2 if cout > 96 else 1, sq)
     mt, nt, wm, wn = (3, 1, 2, 4) if cout > 96 else ((3, 1, 1, 8) if cout > 32 else (1, 1, 1, 4))
     return "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>" % (mt, nt, wm, wn, k, stride, 16 if k == 1 else 4, sq)
