@@ -28,6 +28,15 @@
 
 typedef int64_t i64;
 
+/* fmaf is exact by definition, so a build that inlines the hardware instruction and one
+ * that calls libm give the same bits; the clone only keeps the checker from spending
+ * its time in a function call per multiply-add (resolved at load time by the host CPU) */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define HOST_FMA_CLONES __attribute__((target_clones("default", "avx2,fma")))
+#else
+#define HOST_FMA_CLONES
+#endif
+
 /* erf / exp used by the CDF and quantiser tables: 0 = libm (what the reference's
  * CUDA build would call, up to its own rounding), 1 = the published
  * deterministic polynomials the product uses (include/pconv_detmath.h). */
@@ -880,6 +889,7 @@ static float reduce_xor64(float *s) {
   return s[0];
 }
 
+HOST_FMA_CLONES
 void orc_entropy_conv(const float *input, const float *weight, const float *bias, const float *act_param,
                       float *output, const int *mindex, int kernel_size, int group_in, int group_out,
                       int height, int width, int start_idx, int psum, int inner_shape, int channel, int nout,
@@ -888,7 +898,8 @@ void orc_entropy_conv(const float *input, const float *weight, const float *bias
   const int skernel = kernel_size * kernel_size, half_kernel = kernel_size / 2;
   const i64 index_stride = (i64)(height + 2 * pad_in) * (width + 2 * pad_in);
   const int nblocks = num_out * group_out * inner_shape;
-#pragma omp parallel for
+  const int red = channel * skernel;
+#pragma omp parallel for schedule(static)
   for (int block = 0; block < nblocks; block++) {
     int pb = block % inner_shape;
     int og = (block / inner_shape) % group_out;
@@ -928,24 +939,26 @@ void orc_entropy_conv(const float *input, const float *weight, const float *bias
       }
       sum = reduce_ref128(part);
     } else {
-      const int red = channel * skernel;
+      /* same arithmetic as the plain statement of this order (lane l of 64 walks
+       * kk = l, l+64, ... with kk = tap*channel + ci, skipping ci >= the tap's causal
+       * channel limit): visiting kk in ascending order and adding into lane kk % 64
+       * gives every lane the same fmaf sequence, without decoding kk per element */
       const float *wrow = weight + ((i64)nbatch * nout + pout) * red;
-      for (int lane = 0; lane < 64; lane++) {
-        float s = 0;
-        for (int kk = lane; kk < red; kk += 64) {
-          int ci = kk % channel;
-          int tap = kk / channel;
-          int kw = tap % kernel_size;
-          int kh = tap / kernel_size;
-          int qh = hp - half_kernel + kh;
-          int pw = tw - half_kernel + kw;
-          int nchannel = constrain == 5 ? (psum - qh - pw) * group_in : (psum - qh - pw + 1) * group_in;
-          if (ci < nchannel) {
-            i64 d = ((i64)qn * channel + ci) * index_stride + (i64)(th - half_kernel + kh + pad_in) * (width + 2 * pad_in) + pw + pad_in;
-            s = fmaf(input[d], wrow[ci * skernel + tap], s);
-          }
+      const int wpad = width + 2 * pad_in;
+      const float *base = input + (i64)qn * channel * index_stride + (i64)(th - half_kernel + pad_in) * wpad +
+                          (tw - half_kernel + pad_in);
+      for (int lane = 0; lane < 64; lane++) part[lane] = 0;
+      for (int tap = 0; tap < skernel; tap++) {
+        int kw = tap % kernel_size, kh = tap / kernel_size;
+        int qh = hp - half_kernel + kh, pw = tw - half_kernel + kw;
+        int nchannel = constrain == 5 ? (psum - qh - pw) * group_in : (psum - qh - pw + 1) * group_in;
+        if (nchannel > channel) nchannel = channel;
+        const float *src = base + (i64)kh * wpad + kw;
+        const float *wt = wrow + tap;
+        for (int ci = 0; ci < nchannel; ci++) {
+          const int lane = (tap * channel + ci) & 63;
+          part[lane] = fmaf(src[(i64)ci * index_stride], wt[ci * skernel], part[lane]);
         }
-        part[lane] = s;
       }
       sum = reduce_xor64(part);
     }
@@ -1068,6 +1081,7 @@ void orc_gmm_table(float *weight, float *delta, const float *mean, float *output
 
 /* ---- dense conv: k-ascending fp32 fmaf chain (the product's published order for
  * the nn.Conv2d call sites; torch.nn.functional.conv2d is the 1e-4 reference) ---- */
+HOST_FMA_CLONES
 void orc_conv2d_chain(const float *in, const float *w, const float *bias, const float *slope, float *out,
                       int tn, int cin, int h, int wd, int cout, int k, int stride) {
   const int ho = (h - k) / stride + 1, wo = (wd - k) / stride + 1;

@@ -173,11 +173,21 @@ class CodecEngine(object):
         n = frames.shape[0]
         chunk = self.ENCODE_CHUNK if n > self.ENCODE_CHUNK else n
         pending, out = [], []
-        for k, lo in enumerate(range(0, n, chunk)):
-            sym = self.symbols(frames[lo:lo + chunk]).contiguous()
-            eng = self._engine("enc", sym.shape[2], sym.shape[3], sym.shape[0] // self.enc.ent.npart, slot=k)
-            eng.encode_begin(sym)
-            pending.append(eng)
+        try:
+            for k, lo in enumerate(range(0, n, chunk)):
+                sym = self.symbols(frames[lo:lo + chunk]).contiguous()
+                eng = self._engine("enc", sym.shape[2], sym.shape[3], sym.shape[0] // self.enc.ent.npart, slot=k)
+                eng.encode_begin(sym)
+                pending.append(eng)
+        except BaseException:
+            # a later chunk failed: join the coder threads of the chunks already started, or their
+            # engines would refuse every later encode ("the previous encode has not been ended")
+            for eng in pending:
+                try:
+                    eng.encode_end()
+                except Exception:
+                    pass
+            raise
         for eng in pending:
             out += eng.encode_end()
         return out
@@ -217,7 +227,9 @@ class CodecEngine(object):
             sym = box.pop(k)
             if isinstance(sym, BaseException):
                 raise sym
-            torch.cuda.current_stream(self.device).wait_stream(side)
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(side)
+            sym.record_stream(main)  # allocated on `side`, read by the synthesis transform on `main`
             worker = None
             if k + 1 < len(chunks):
                 worker = threading.Thread(target=run, args=(k + 1,))

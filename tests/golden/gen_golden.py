@@ -9,6 +9,11 @@ authoring container:
   torch_helpers.npz  GDN.LowerBound, pytorch_ssim.SSIM(11,3), StubMask.Extract
                   outputs on seeded inputs (pure-torch files imported by path)
 
+  reference_graph.npz  the reference's OWN model_zoo_v2.py (EncoderV2, DecoderV2,
+                  CMPNetV2MF; imported by path, unchanged) run on this repo's drop-in
+                  modules with the CPU oracle underneath: state_dict key -> shape maps,
+                  a checksum per seeded parameter, and the outputs on seeded inputs
+
 The fixtures are data (inputs + expected outputs); no reference source is copied.
 Run from the repo root:  python tests/golden/gen_golden.py
 """
@@ -101,8 +106,81 @@ def torch_fixtures():
     print("torch helpers: LowerBound, SSIM=%.6f, Extract" % s.item())
 
 
+# ---- the reference graph on the drop-in (model_zoo_v2.py:129-211, 322-334) ------------------
+GRAPH_SEED = 1234          # torch.manual_seed before each model is constructed
+GRAPH_INPUT_SEED = 5
+GRAPH_SIZES = {"small": (256, 512), "ref": (512, 1024)}   # (H, W); "ref" = the reference codec's own frame size
+GRAPH_STRIDE = 37          # outputs larger than 64k elements are stored as every 37th element + checksums
+
+
+def graph_models(zoo, operators, which):
+    """the three graphs, each built right after torch.manual_seed(GRAPH_SEED)"""
+    torch.manual_seed(GRAPH_SEED)
+    if which == "CMPNetV2MF":
+        return zoo.CMPNetV2MF(56, 192, 192, 16, 8, True, False, 0)
+    ctx = operators.PseudoContextV2(16, True, device=0)
+    cls = zoo.EncoderV2 if which == "EncoderV2" else zoo.DecoderV2
+    return cls(192, 192, 16, ctx, 0)
+
+
+def graph_inputs(which, size):
+    H, W = GRAPH_SIZES[size]
+    g = torch.Generator().manual_seed(GRAPH_INPUT_SEED)
+    if which == "EncoderV2":
+        return torch.rand(16, 3, H // 16, W, generator=g)
+    if which == "DecoderV2":
+        return torch.rand(16, 192, H // 256, W // 16, generator=g)
+    return torch.rand(1, 3, H, W, generator=g)
+
+
+def graph_record(t):
+    """what the fixture keeps of an output tensor"""
+    flat = t.detach().reshape(-1).to(torch.float32)
+    d = flat.double()
+    keep = flat if flat.numel() <= 65536 else flat[::GRAPH_STRIDE]
+    return {"shape": np.array(t.shape, np.int64), "values": keep.numpy().copy(),
+            "sum": np.array(d.sum().item()), "abs_sum": np.array(d.abs().sum().item()),
+            "sq_sum": np.array((d * d).sum().item())}
+
+
+GRAPH_CASES = [("EncoderV2", "small"), ("DecoderV2", "small"), ("CMPNetV2MF", "small"),
+               ("EncoderV2", "ref"), ("DecoderV2", "ref"), ("CMPNetV2MF", "ref")]
+
+
+def graph_fixtures():
+    import pseudocylindrical_convolution_amd as pkg
+    from pseudocylindrical_convolution_amd.PCONV_operator import backend
+    from oracle import pconv_cpu, coder_cpu
+    backend.use(pconv_cpu, coder_cpu)
+    pconv_cpu.set_detmath(True)
+    pkg.install_dropin()
+    ref_zoo = load(os.path.join(REF, "model_zoo_v2.py"), "ref_model_zoo_v2")   # its imports resolve to the drop-in
+    import PCONV_operator as operators
+    out = {}
+    try:
+        for which in ("EncoderV2", "DecoderV2", "CMPNetV2MF"):
+            sd = graph_models(ref_zoo, operators, which).state_dict()
+            out["%s/keys" % which] = np.array(list(sd))
+            out["%s/shapes" % which] = np.array([list(v.shape) + [-1] * (5 - v.dim()) for v in sd.values()], np.int64)
+            out["%s/param_sums" % which] = np.array([v.double().sum().item() for v in sd.values()])
+        for which, size in GRAPH_CASES:
+            net = graph_models(ref_zoo, operators, which).eval()
+            with torch.no_grad():
+                res = net(graph_inputs(which, size))
+            res = res if isinstance(res, tuple) else (res,)
+            for i, t in enumerate(res):
+                for k, v in graph_record(t).items():
+                    out["%s/%s/out%d/%s" % (which, size, i, k)] = v
+            print("graph", which, size, [tuple(t.shape) for t in res])
+    finally:
+        backend.reset()
+    np.savez_compressed(os.path.join(OUT, "reference_graph.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    coder_fixtures()
-    weight_fixtures()
-    torch_fixtures()
+    if "--graph-only" not in sys.argv:
+        coder_fixtures()
+        weight_fixtures()
+        torch_fixtures()
+    graph_fixtures()
