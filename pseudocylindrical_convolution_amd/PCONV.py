@@ -10,6 +10,7 @@ libpconv_hip.so through the C ABI in include/pconv_hip.h.
 There is no CPU path here: every forward needs the HIP library and a GPU tensor.
 """
 import ctypes
+import functools
 import weakref
 
 import numpy as np
@@ -67,9 +68,37 @@ def tile_widths(weight, npart, height, width):
     return out
 
 
+def _timed(method, label):
+    """`timeit=True` of the reference's constructors (timer.h:5-47: events around the kernels of a
+    call, then `<head> Elapsed time : <ms> ms` on stdout): here around the whole forward / backward
+    call of the op, on the stream the op launches on"""
+
+    @functools.wraps(method)
+    def run(self, *args, **kwargs):
+        if not self.timeit_:
+            return method(self, *args, **kwargs)
+        stream = torch.cuda.current_stream(self._dev())
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(stream)
+        try:
+            return method(self, *args, **kwargs)
+        finally:
+            stop.record(stream)
+            stop.synchronize()
+            print("%s.%s Elapsed time : %f ms" % (type(self).__name__, label, start.elapsed_time(stop)))
+
+    return run
+
+
 class _Op(object):
     """State shared by all ops: target device and re-used output buffers
     (base_opt.hpp:12-72)."""
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        for name, attr in list(vars(cls).items()):
+            if callable(attr) and (name.startswith("forward") or name.startswith("backward")):
+                setattr(cls, name, _timed(attr, name))
 
     def __init__(self, device, timeit=False):
         self.device_ = int(device)

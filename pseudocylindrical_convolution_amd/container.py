@@ -16,8 +16,11 @@ payload -- the payload itself is byte for byte the reference-format stream:
     10      2     ERP width / 16, little endian
     12      4     payload length in bytes, little endian
 
-`--raw` on the command line keeps the reference's headerless files.
+The command line writes the reference's headerless files unless `--container` is given;
+decoding recognises a container by `sniff` (magic, version and a payload length that
+matches the file), so headerless files produced by the reference decode as before.
 """
+import os
 import struct
 
 MAGIC = b"PCVC"
@@ -51,7 +54,7 @@ def unpack(data):
         raise ContainerError("file shorter than the %d-byte header" % HEADER_BYTES)
     magic, version, flags, model_idx, ngroup, h16, w16, n = struct.unpack(_FMT, data[:HEADER_BYTES])
     if magic != MAGIC:
-        raise ContainerError("no container magic: a headerless reference-format stream? (decode it with --raw)")
+        raise ContainerError("no container magic: a headerless reference-format stream?")
     if version != VERSION:
         raise ContainerError("container version %d, this build reads %d" % (version, VERSION))
     if len(data) - HEADER_BYTES != n:
@@ -60,6 +63,25 @@ def unpack(data):
         raise ContainerError("empty field in the header")
     return ({"height": h16 * 16, "width": w16 * 16, "model_idx": model_idx, "ssim": bool(flags & 1),
              "valid_dim": ngroup * 4}, bytes(data[HEADER_BYTES:]))
+
+
+def sniff(path):
+    """header dict when the file is a well-formed container, else None (a headerless stream).
+    A raw arithmetic-coded stream passes for a container only if its first 16 bytes happen to
+    spell the magic, the version and its own length: 2^-72 for random bytes."""
+    try:
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            head = f.read(HEADER_BYTES)
+        if len(head) < HEADER_BYTES or head[:4] != MAGIC:
+            return None
+        magic, version, flags, model_idx, ngroup, h16, w16, n = struct.unpack(_FMT, head)
+        if version != VERSION or n != size - HEADER_BYTES or not (h16 and w16 and ngroup):
+            return None
+        return {"height": h16 * 16, "width": w16 * 16, "model_idx": model_idx, "ssim": bool(flags & 1),
+                "valid_dim": ngroup * 4}
+    except OSError:
+        return None
 
 
 def read(path):

@@ -248,11 +248,15 @@ class PseudoDecoder(nn.Module):
             code_f[:, :self.valid_dim] = code_ext
             return self.clip(self.uslice(self.decoder(code_f.contiguous())))
 
-    def forward(self, code_name, height=512, width=1024, raw=True):
+    def forward(self, code_name, height=512, width=1024, raw=None):
         """code file -> image; the entropy stage on the native engine when on the GPU
-        (see PseudoEncoder.forward).  raw=False: the file carries the container header
-        (container.py) and height / width are read from it."""
+        (see PseudoEncoder.forward).  raw=True: the reference's headerless stream, size from the
+        arguments; raw=False: the file carries the container header (container.py) and height /
+        width are read from it; raw=None (default): a file that starts with a valid container
+        header is read as one, anything else as a raw stream."""
         with torch.no_grad():
+            if raw is None:
+                raw = container.sniff(code_name) is None
             if not raw:
                 head, payload = container.read(code_name)
                 if head["valid_dim"] != self.valid_dim:
@@ -352,17 +356,22 @@ def _pick(model_idx, mse):
 
 
 def bitrate(path, height=512, width=1024):
-    return os.path.getsize(path) * 8 / float(width) / float(height)
+    """bits per pixel of the coded payload (a container header is not counted, so the figure is
+    the reference's `os.path.getsize(fc)*8/1024./512.` for the same stream, pseudo_codec.py:247,283)"""
+    head = container.sniff(path)
+    nbytes = os.path.getsize(path) - (container.HEADER_BYTES if head is not None else 0)
+    return nbytes * 8 / float(width) / float(height)
 
 
-def encoding(img_list, out_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, raw=False):
-    """raw=True writes the reference's headerless files; the default adds the 16-byte
-    container header so that the file decodes without any size / model argument"""
+def encoding(img_list, out_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, boxed=False):
+    """reference: pseudo_codec.py:236-247.  The files are the reference's headerless streams unless
+    boxed=True (--container): then the 16-byte header of container.py goes in front of the same
+    payload and the file decodes without any size / model argument."""
     prex, vd, model_dir = _pick(model_idx, mse)
     dev = backend.device_of(device_id)
     t1 = PseudoEncoder(vd, device_id=device_id).to(dev)
     load_models(t1, '{}/{}_encoder.pt'.format(model_dir, prex), '{}/{}_ent.pt'.format(model_dir, prex), dev)
-    header = None if raw else {"model_idx": model_idx, "ssim": not mse}
+    header = {"model_idx": model_idx, "ssim": not mse} if boxed else None
     for fn, fo in zip(img_list, out_list):
         data = img2tensor(check_img(read_image(fn), height, width), dev)
         t1(data, fo, header)
@@ -370,10 +379,10 @@ def encoding(img_list, out_list, model_idx=0, mse=True, device_id=0, height=512,
 
 
 def _decoder_for(code_list, model_idx, mse, device_id, raw):
-    """decoder with its checkpoint loaded; with container files the model is the one
-    the FIRST file names (all files of a call must agree)"""
-    if not raw:
-        head, _ = container.read(code_list[0])
+    """decoder with its checkpoint loaded.  When the FIRST file carries a container header the
+    model is the one it names (all container files of a call must agree); raw=True never looks"""
+    head = None if raw else container.sniff(code_list[0])
+    if head is not None:
         model_idx, mse = head["model_idx"], not head["ssim"]
     prex, vd, model_dir = _pick(model_idx, mse)
     dev = backend.device_of(device_id)
@@ -382,19 +391,23 @@ def _decoder_for(code_list, model_idx, mse, device_id, raw):
     return t1, dev, model_idx, mse
 
 
-def _check_same_model(fc, model_idx, mse):
-    head, _ = container.read(fc)
+def _file_geometry(fc, model_idx, mse, height, width, raw):
+    """(height, width, is_raw) of one code file: from its container header when it has one (which
+    must name the model the decoder was built for), else from the arguments"""
+    head = None if raw else container.sniff(fc)
+    if head is None:
+        return height, width, True
     if head["model_idx"] != model_idx or head["ssim"] == mse:
         raise container.ContainerError("%s was coded with another model than the first file of the list" % fc)
-    return head
+    return head["height"], head["width"], False
 
 
 def decoding(code_list, decoded_img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, raw=False):
+    """reference: pseudo_codec.py:249-260"""
     t1, dev, model_idx, mse = _decoder_for(code_list, model_idx, mse, device_id, raw)
     for fc, fo in zip(code_list, decoded_img_list):
-        if not raw:
-            _check_same_model(fc, model_idx, mse)
-        write_image(fo, tensor2img(t1(fc, height, width, raw)))
+        h, w, is_raw = _file_geometry(fc, model_idx, mse, height, width, raw)
+        write_image(fo, tensor2img(t1(fc, h, w, is_raw)))
         print('Decoding {}, output to {}'.format(fc, fo))
 
 
@@ -415,22 +428,22 @@ class ViewportMetrics(object):
 
 
 def decoding_and_test(code_list, img_list, model_idx=0, mse=True, device_id=0, height=512, width=1024, raw=False):
+    """reference: pseudo_codec.py:263-290"""
     t1, dev, model_idx, mse = _decoder_for(code_list, model_idx, mse, device_id, raw)
     metrics = ViewportMetrics(device_id)
     rows = []
     for fc, fn in zip(code_list, img_list):
-        if not raw:
-            head = _check_same_model(fc, model_idx, mse)
-            height, width = head["height"], head["width"]
-        rdata = t1(fc, height, width, raw)
-        data = img2tensor(check_img(read_image(fn), height, width), dev)
+        h, w, is_raw = _file_geometry(fc, model_idx, mse, height, width, raw)
+        rdata = t1(fc, h, w, is_raw)
+        data = img2tensor(check_img(read_image(fn), h, w), dev)
         pr, vssim = metrics(data, rdata)
-        rt = bitrate(fc, height, width)
+        rt = bitrate(fc, h, w)
         rows.append((rt, pr, vssim))
         print('Decoding {}, compare it to {} \n Bitrate:{:.3f}bpp, PSNR:{:.2f}dB, SSIM:{:.4f}'.format(fc, fn, rt, pr, vssim))
     print('-' * 53 + '\nAverage Performance\n' + '-' * 53)
     rt, pr, vssim = np.average(np.array(rows), axis=0)
     print('Bitrate:{:.3f}bpp, PSNR:{:.2f}dB, SSIM:{:.4f}'.format(rt, pr, vssim))
+    return rows
 
 
 def read_list(fname):
@@ -462,9 +475,12 @@ def main(argv=None):
     parser.add_argument('--gpu-id', type=int, default=0, help='The graphic card id for encoding and decoding.')
     parser.add_argument('--height', type=int, default=512, help='ERP height of the coded image (multiple of 256)')
     parser.add_argument('--width', type=int, default=1024, help='ERP width of the coded image (multiple of 16)')
+    parser.add_argument('--container', action='store_true', default=False,
+                        help='Encoding: put a 16-byte header (size, model, valid_dim, length) in front of the stream, so '
+                             "that the file decodes without --height/--width/--model-idx/--ssim.  Default: the reference's "
+                             'headerless files.  Decoding recognises such files by their magic')
     parser.add_argument('--raw', action='store_true', default=False,
-                        help="Headerless code files, the reference's format (size and model then come from the flags); "
-                             'default: files carry a 16-byte header (size, model, valid_dim, length)')
+                        help='Decoding: never look for a container header (size and model from the flags)')
     args = parser.parse_args(argv)
     check_models()
     midx = args.model_idx
@@ -477,22 +493,22 @@ def main(argv=None):
     pick = lambda lst, fil: lst if lst is not None else (read_list(fil) if fil is not None else None)
     img_list, code_list, out_list = pick(args.img_list, args.img_file), pick(args.code_list, args.code_file), \
         pick(args.out_list, args.out_file)
-    size = dict(height=args.height, width=args.width, raw=args.raw)
+    size = dict(height=args.height, width=args.width)
     if args.enc:
         assert img_list is not None, 'No input images for encoding'
         assert code_list is not None, 'No code files for saving the codes'
         assert len(img_list) == len(code_list), 'The number of images and codes should be the same'
-        encoding(img_list, code_list, midx, not args.ssim, args.gpu_id, **size)
+        encoding(img_list, code_list, midx, not args.ssim, args.gpu_id, boxed=args.container and not args.raw, **size)
     else:
         assert code_list is not None, 'No code files for decoding'
         if args.dec:
             assert out_list is not None, 'No out files for saving the decoded images'
             assert len(code_list) == len(out_list), 'The number of codes and reconstructed images should be the same'
-            decoding(code_list, out_list, midx, not args.ssim, args.gpu_id, **size)
+            decoding(code_list, out_list, midx, not args.ssim, args.gpu_id, raw=args.raw, **size)
         else:
             assert img_list is not None, 'No source images for evaluation.'
             assert len(code_list) == len(img_list), 'The number of codes and corresponding source images should be the same'
-            decoding_and_test(code_list, img_list, midx, not args.ssim, args.gpu_id, **size)
+            decoding_and_test(code_list, img_list, midx, not args.ssim, args.gpu_id, raw=args.raw, **size)
 
 
 if __name__ == '__main__':

@@ -74,7 +74,8 @@ def train(args, model, device, train_loader, optimizer, optimizer_quant, epoch, 
         param = list(get_params(model, ent))
         if batch_idx % acc_batch == acc_batch - 1:
             acc_grad.copy_back(param)
-            torch.nn.utils.clip_grad_norm_(param, clip)
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(param, clip)
             optimizer.step()
         else:
             acc_grad.acc(param)
@@ -170,10 +171,21 @@ def Job(rank, world_size, args):
     wrap = lambda m: DDP(m.to(device), [cid] if on_gpu else None)
     best, latest = '{}/{}_best_0.pt'.format(save_dir, prex), '{}/{}_latest.pt'.format(save_dir, prex)
     if args.init:
-        of = best if os.path.exists(best) else (args.init_from or '')
+        # stage 2 trains the entropy model on top of the stage-1 transforms: an own checkpoint of this
+        # stage, else --init-from, else what `--base` wrote (trainDDP_Full.py:118-122 loads
+        # save_models/base_opt_192_{valid_dim}_16_best_0.pt).  Never from random transforms.
+        base_best = '{}/base_{}_{}_{}_{}_best_0.pt'.format(save_dir, 'opt' if args.opt else 'normal', args.channels,
+                                                           args.valid_dim, args.npart)
+        of = best if os.path.exists(best) else (args.init_from or base_best)
+        if not os.path.exists(of) and not args.init_random:
+            raise FileNotFoundError(
+                '--init needs the stage-1 transforms: no checkpoint at {} (run --base first or pass --init-from; '
+                '--init-random trains on random transforms, for smoke runs only)'.format(of))
         if os.path.exists(of):
             init_with_trained_model(of, model, device)
             log.log('load init model {} successful...'.format(of))
+        else:
+            log.log('WARNING: --init-random: no stage-1 checkpoint at {}, the entropy model is trained on RANDOM transforms'.format(of))
         model = wrap(model)
     elif os.path.exists(best):
         of = latest if (args.latest and os.path.exists(latest)) else best
@@ -230,7 +242,10 @@ def build_parser():
     parser.add_argument('--gamma', type=float, default=1, help='trade-off of MSE loss')
     parser.add_argument('--beta', type=float, default=0, help='trade-off of SSIM loss')
     parser.add_argument('--alpha', type=float, default=1, help='trade-off of rate loss')
-    parser.add_argument('--clip', type=float, default=0.1)
+    parser.add_argument('--clip', type=float, default=0.1,
+                        help='global gradient-norm clip per optimiser step; 0 = none.  (The reference passes an exhausted '
+                             'generator to clip_grad_norm_, trainDDP_Full.py:43-46, so its runs are in effect unclipped: '
+                             'use --clip 0 to reproduce them)')
     parser.add_argument('--opt', action='store_true', default=True, help='optimised tile split')
     parser.add_argument('--no-opt', dest='opt', action='store_false')
     parser.add_argument('--init', action='store_true', default=False,
@@ -246,6 +261,8 @@ def build_parser():
     parser.add_argument('--mean', type=float, default=1.5, help="the sampler's minimum mean image value per step")
     parser.add_argument('--base-dir', default='.', help='checkpoints and logs go to <base-dir>/save_models')
     parser.add_argument('--init-from', default=None, help='checkpoint to initialise from')
+    parser.add_argument('--init-random', action='store_true', default=False,
+                        help='--init without a stage-1 checkpoint: go on from random transforms (smoke runs only)')
     parser.add_argument('--data-dir', default='./360_512')
     parser.add_argument('--train-list', default=None)
     parser.add_argument('--test-list', default=None)

@@ -1,0 +1,94 @@
+"""The command-line driver end to end (reference: pseudo_codec.py:236-290, 310-356):
+random CMPNetV2MF -> export.export_codec -> `pseudo_codec.main([...])` --enc / --dec / --test on
+PNG files, in the reference's headerless format (sizes from the flags) and with the container
+header (no size flags on decode).  CPU: on the oracle backend at 256x512.  GPU: the HIP path at
+512x1024 and 1024x2048."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_png(path, H, W, seed):
+    from PIL import Image
+    g = np.random.default_rng(seed)
+    yy = np.linspace(0, 1, H)[:, None, None]
+    xx = np.linspace(0, 1, W)[None, :, None]
+    ph = g.random(3)[None, None, :] * 6.28
+    img = 0.5 + 0.25 * np.sin(6.28318 * 3 * xx + ph) * np.cos(3.14159 * 2 * yy) + 0.08 * (g.random((H, W, 3)) - 0.5)
+    Image.fromarray((img.clip(0, 1) * 255).astype(np.uint8)).save(path)
+
+
+def _models(tmp_path):
+    """demo/ssim/4_56_{encoder,decoder,ent}.pt (model-idx 3 of the --ssim list) from a seeded random
+    training graph, and the two files check_models() looks for"""
+    from pseudocylindrical_convolution_amd import export, model_zoo_v2 as zoo
+    torch.manual_seed(77)
+    net = zoo.CMPNetV2MF(56, 192, 192, 16, 8, True, False, 0)
+    state = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    export.export_codec(state, 56, str(tmp_path / "demo" / "ssim"), "4_56")
+    export.export_codec(state, 56, str(tmp_path / "demo" / "ssim"), "1_56")
+    export.export_codec(state, 56, str(tmp_path / "demo" / "mse"), "1_56")
+
+
+def _drive(tmp_path, monkeypatch, capsys, sizes, device):
+    from pseudocylindrical_convolution_amd import pseudo_codec as PC, container
+    monkeypatch.chdir(tmp_path)
+    _models(tmp_path)
+    common = ["--ssim", "--model-idx", "3"]
+    for k, (H, W) in enumerate(sizes):
+        src, raw, boxed = "img%d.png" % k, "code%d.bin" % k, "code%d.pcv" % k
+        _write_png(src, H, W, k)
+        size = ["--height", str(H), "--width", str(W)]
+        # --enc: the reference's headerless file, then the same with the container header
+        PC.main(["--enc", "--img-list", src, "--code-list", raw] + common + size)
+        PC.main(["--enc", "--container", "--img-list", src, "--code-list", boxed] + common + size)
+        out = capsys.readouterr().out
+        with open(raw, "rb") as f:
+            payload = f.read()
+        head, body = container.read(boxed)
+        assert body == payload                                     # container payload == the raw file
+        assert head == {"height": H, "width": W, "model_idx": 3, "ssim": True, "valid_dim": 56}
+        assert container.sniff(raw) is None and container.sniff(boxed) == head
+        bpp = len(payload) * 8 / float(H * W)
+        printed = [float(v) for v in re.findall(r"bitrate: ([0-9.]+)bpp", out)]
+        assert printed == [round(bpp, 3), round(bpp, 3)]           # the header is not counted
+        # --dec: container with NO size / model flags; raw stream with the flags
+        PC.main(["--dec", "--code-list", boxed, "--out-list", "boxed%d.png" % k])
+        PC.main(["--dec", "--code-list", raw, "--out-list", "raw%d.png" % k] + common + size)
+        PC.main(["--dec", "--raw", "--code-list", raw, "--out-list", "raw_flag%d.png" % k] + common + size)
+        a, b, c = (PC.read_image(p % k) for p in ("boxed%d.png", "raw%d.png", "raw_flag%d.png"))
+        assert a.shape == (H, W, 3) and np.array_equal(a, b) and np.array_equal(a, c)
+        # == PseudoDecoder on the same checkpoint
+        dec = PC.PseudoDecoder(56, 0).to(device)
+        PC.load_models(dec, "demo/ssim/4_56_decoder.pt", "demo/ssim/4_56_ent.pt", device)
+        assert np.array_equal(PC.tensor2img(dec(raw, H, W))[:, :, ::-1], a[:, :, ::-1])
+        capsys.readouterr()
+        # --test: prints bitrate / PSNR / SSIM per file and the average
+        rows = PC.decoding_and_test([boxed], [src], 3, False, 0)
+        rows_raw = PC.decoding_and_test([raw], [src], 3, False, 0, H, W)
+        assert rows == rows_raw and abs(rows[0][0] - bpp) < 1e-12
+        PC.main(["--test", "--code-list", boxed, "--img-list", src])
+        out = capsys.readouterr().out
+        assert re.findall(r"Bitrate:([0-9.]+)bpp", out)[-1] == "%.3f" % bpp
+        assert "Average Performance" in out
+        # the decoded PNG really is the evaluated reconstruction: its own PSNR against the source
+        mse = np.mean((a.astype(np.float64) - PC.read_image(src).astype(np.float64)) ** 2) / 255. ** 2
+        assert np.isfinite(mse) and mse > 0
+    # a container coded with another model than the one the list starts with is refused
+    other = "other.pcv"
+    with open("code0.bin", "rb") as f:
+        container.write(other, f.read(), height=sizes[0][0], width=sizes[0][1], model_idx=0, ssim=True, valid_dim=56)
+    with pytest.raises(container.ContainerError):
+        PC.decoding(["code0.pcv", other], ["x.png", "y.png"])
+
+
+def test_cli_end_to_end_on_the_oracle(oracle_backend, tmp_path, monkeypatch, capsys):
+    _drive(tmp_path, monkeypatch, capsys, [(256, 512)], "cpu")
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_on_the_gpu(hip_backend, tmp_path, monkeypatch, capsys):
+    _drive(tmp_path, monkeypatch, capsys, [(512, 1024), (1024, 2048)], "cuda:0")

@@ -213,3 +213,34 @@ def test_exported_checkpoint_codes_at_the_rate_the_training_graph_predicts(oracl
     a, b = torch.load(paths[2]), torch.load(again[2])
     assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
     assert a["ent.net.0.conv.weight"].shape == (3, 6, 2, 5, 5)
+
+
+def _init_stage_job(base_dir, extra, port):
+    import torch.distributed as dist
+    from pseudocylindrical_convolution_amd import train
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    args = train.build_parser().parse_args(
+        ["--device", "cpu", "--synthetic", "2", "--height", "256", "--width", "512", "--batch-size", "1",
+         "--test-batch-size", "1", "--epochs", "0", "--valid-dim", "8", "--channels", "16", "--code-dim", "16",
+         "--viewport_size", "24", "--workers", "0", "--no-opt", "--base-dir", base_dir, "--init"] + extra)
+    try:
+        return train.Job(0, 1, args)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_init_stage_starts_from_the_base_stage_checkpoint(oracle_backend, tmp_path):
+    """--init (entropy model on frozen transforms) loads what --base wrote
+    (trainDDP_Full.py:118-122: save_models/base_opt_192_{valid_dim}_16_best_0.pt) and refuses to go on
+    from random transforms when nothing is there"""
+    port = 31000 + os.getpid() % 2000
+    with pytest.raises(FileNotFoundError):
+        _init_stage_job(str(tmp_path), [], port)
+    assert _init_stage_job(str(tmp_path), ["--init-random"], port + 1) == []
+    base = _tiny(oracle_backend, cls="CMPNetV2M")
+    os.makedirs(os.path.join(str(tmp_path), "save_models"), exist_ok=True)
+    torch.save(base.state_dict(), os.path.join(str(tmp_path), "save_models", "base_normal_16_8_16_best_0.pt"))
+    assert _init_stage_job(str(tmp_path), [], port + 2) == []
+    log = open(os.path.join(str(tmp_path), "save_models", "ent_normal_16_8_16_init_logs_0.txt")).read()
+    assert "base_normal_16_8_16_best_0.pt successful" in log
