@@ -39,8 +39,9 @@ import torch.distributed as dist
 
 VALID_FRACTION = 836.0 / 1024.0      # valid columns / all columns
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md, dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md, HBM3E
 MODEL_VALID_DIM = 56                 # model-idx 3 of the --ssim list (pseudo_codec.py:18-19)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_bench_pmc.json")
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("round3_bench_pmc.json", "round2_bench_pmc.json")]
 
 
 # ----------------------------------------------------------------------------
@@ -52,6 +53,54 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def rank_cpus(local_rank, local_world, allowed=None):
+    """the slice of the allowed CPUs that rank `local_rank` of `local_world` ranks on this node
+    keeps: contiguous, disjoint, every rank at least one (the rest of the division goes to the
+    first ranks).  With fewer CPUs than ranks the ranks share all of them."""
+    cpus = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    base, extra = divmod(len(cpus), local_world)
+    lo = local_rank * base + min(local_rank, extra)
+    return cpus[lo:lo + base + (1 if local_rank < extra else 0)]
+
+
+def cpu_quota():
+    """CPUs the cgroup lets this job use (a GPU box shows all host CPUs in the affinity mask of a
+    container that owns a share of them); None when there is no quota"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        return max(1, quota // period) if quota > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def pin_rank(local_rank, local_world):
+    """Before this rank creates any thread or touches the GPU: keep it (and every thread it starts:
+    torch's intra-op pool, the engine's queueing / polling / coder threads) on its own slice of the
+    host cores, so that 8 ranks x (2 drivers + up to 8 coder threads + OpenMP) do not migrate over
+    each other's cores.  PCONV_BENCH_PIN=0 turns it off.  Returns the number of cores kept."""
+    if not hasattr(os, "sched_setaffinity") or os.environ.get("PCONV_BENCH_PIN", "1") == "0":
+        return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpus = rank_cpus(local_rank, local_world)
+    os.sched_setaffinity(0, cpus)
+    quota = cpu_quota()
+    n = max(1, len(cpus) if quota is None else min(len(cpus), max(1, quota // max(local_world, 1))))
+    n = min(n, 32)   # the host side of a rank is a handful of driver / coder threads; torch's pool never needs more
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    torch.set_num_threads(n)
+    return n
 
 
 def launch_ranks(nproc, argv, script=None, env=None):
@@ -112,6 +161,10 @@ class ConvProbe(object):
     def __init__(self):
         self.records = []
 
+    def summarise_bytes(self):
+        """per kernel of the HBM-bound ops: algorithmic bytes, seconds, launches, and the same per class"""
+        return self.summarise()
+
     def summarise(self):
         torch.cuda.synchronize()
         per = {}
@@ -128,19 +181,27 @@ class ConvProbe(object):
         return per
 
 
+def _pmc_record(kernel):
+    for path in PMC_SUMMARIES:
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            pmc = json.load(f)
+        rec = pmc.get("kernels", {}).get(kernel)
+        if rec:
+            return rec, path
+    return None, None
+
+
 def pmc_evidence(kernel, avg_flops):
     """HBM bytes per launch and matrix-pipe busy fraction of `kernel` from the tracked
     rocprofv3 --pmc summary (tools/summarise_pmc.py over separate counter passes of this
     very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC counters
     cannot be read from inside the process; a summary of another kernel is not used."""
-    if not os.path.exists(PMC_SUMMARY):
-        return {}
-    with open(PMC_SUMMARY) as f:
-        pmc = json.load(f)
-    rec = pmc.get("kernels", {}).get(kernel)
+    rec, path = _pmc_record(kernel)
     if not rec:
         return {}
-    out = {"traffic_source": "profiles/%s" % os.path.basename(PMC_SUMMARY)}
+    out = {"traffic_source": "profiles/%s" % os.path.basename(path)}
     if rec.get("hbm_bytes_per_launch") is not None:
         out["traffic"] = int(rec["hbm_bytes_per_launch"])
         if rec.get("algorithmic_flops_per_launch"):
@@ -151,16 +212,41 @@ def pmc_evidence(kernel, avg_flops):
     return out
 
 
+def hbm_table(per_kernel):
+    """rows for the HBM-bound gather / permute kernels (north_star: slice / pseudo_pad / pseudo_fill /
+    uslice ... against the HBM roof): algorithmic bytes of SURVEY 8d per launch / event time"""
+    rows = []
+    for kernel, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]["seconds"]):
+        n = d["launches"]
+        gbs = d["flops"] / d["seconds"] / 1e9            # the probe's work column holds bytes here
+        row = {"kernel": kernel, "launches": n, "avg_launch_us": round(d["seconds"] / n * 1e6, 2),
+               "mb_per_launch": round(d["flops"] / n / 1e6, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+        rec, path = _pmc_record(kernel)
+        if rec and rec.get("hbm_bytes_per_launch") is not None:
+            row["traffic"] = int(rec["hbm_bytes_per_launch"])
+            row["traffic_source"] = "profiles/%s" % os.path.basename(path)
+        worst = max(d["classes"].items(), key=lambda kv: kv[1][1])
+        row["largest_class"] = {"class": worst[0], "launches": worst[1][2],
+                                "avg_launch_us": round(worst[1][1] / worst[1][2] * 1e6, 2),
+                                "achieved": round(worst[1][0] / worst[1][1] / 1e9, 1)}
+        rows.append(row)
+    return rows
+
+
 def cpu_baseline(sample_h, sample_w):
-    """CPU oracle port of the same encode+decode on one bounded frame, all host threads
-    torch is given; transform / entropy splits as BASELINE.md section 2 asks"""
+    """CPU oracle port of the same encode+decode on one bounded frame on the host cores this
+    process may use: the oracle's C kernels run their output loops under OpenMP, the dense
+    convolutions are torch's CPU library kernels; transform / entropy splits as BASELINE.md
+    section 2 asks, threads of every leg reported"""
     from pseudocylindrical_convolution_amd.PCONV_operator import backend
     from pseudocylindrical_convolution_amd.pseudo_codec import latent_shape
     from oracle import pconv_cpu, coder_cpu
     backend.use(pconv_cpu, coder_cpu)
     pconv_cpu.set_detmath(True)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = pconv_cpu.host_cpu_share()   # affinity mask cut down to the cgroup's CPU quota
     threads = max(1, min(cores, 32))     # oneDNN on these small tensors stops scaling long before 128
+    omp_threads = pconv_cpu.set_num_threads(threads)
     before = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
@@ -184,9 +270,11 @@ def cpu_baseline(sample_h, sample_w):
         torch.set_num_threads(before)
         backend.reset()
     dt = t4 - t0
-    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": threads, "kind": "port",
-            "sample": "1 frame %dx%d enc+dec, %.1f s (oracle C kernels single-threaded + torch CPU conv on %d threads)"
-                      % (sample_w, sample_h, dt, threads),
+    return {"value": sample_h * sample_w / dt / 1e6, "unit": "MPix/s", "cores": max(threads, omp_threads), "kind": "port",
+            "sample": "1 frame %dx%d enc+dec, %.1f s (oracle C kernels on %d OpenMP threads, arithmetic coder 1 thread, "
+                      "torch CPU conv on %d threads)" % (sample_w, sample_h, dt, omp_threads, threads),
+            "threads": {"analysis": threads, "entropy_encode": omp_threads, "entropy_decode": omp_threads,
+                        "synthesis": threads},
             "split_s": {"analysis": round(t1 - t0, 2), "entropy_encode": round(t2 - t1, 2),
                         "entropy_decode": round(t3 - t2, 2), "synthesis": round(t4 - t3, 2)}}
 
@@ -202,7 +290,8 @@ class CodecWorkload(object):
         self.H, self.W, self.F = args.height, args.width, args.frames_per_gpu
         self.enc, self.dec = make_codec(local)
         self.codec = CodecEngine(MODEL_VALID_DIM, local, self.enc, self.dec)
-        self.frames = torch.cat([synthetic_frame(self.H, self.W, 100 + rank * self.F + i, dev)
+        first, stride = getattr(args, "first_frame", rank * self.F), getattr(args, "frame_stride", 1)
+        self.frames = torch.cat([synthetic_frame(self.H, self.W, 100 + first + i * stride, dev)
                                  for i in range(self.F)], 0)
         self.bits_first, self.bits, self.rec, self.streams = None, 0, None, None
         self.local = local
@@ -283,10 +372,13 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--frames-per-gpu", type=int, default=None,
                     help="frames each rank codes per step, in lock-step through the entropy wavefront")
+    ap.add_argument("--frames-total", type=int, default=None,
+                    help="strong scaling: this many frames per step over ALL ranks (BASELINE config #5: 64), "
+                         "rank r takes frames r::world; overrides --frames-per-gpu")
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed passes before the warm-up so that the caching allocator reaches steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="512x1024", help="HxW of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="1024x2048", help="HxW of the CPU baseline sample")
     ap.add_argument("--no-check", action="store_true", help="skip the round-trip / stationarity assertions")
     args = ap.parse_args(argv)
     if args.height is None:
@@ -304,6 +396,15 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = device_type == "cuda"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cores = pin_rank(local, local_world)   # before any thread of this rank exists
+    strong = args.frames_total is not None
+    if strong:
+        if args.frames_total < world:
+            raise SystemExit("--frames-total %d: fewer frames than ranks (%d)" % (args.frames_total, world))
+        args.first_frame = rank
+        args.frame_stride = world
+        args.frames_per_gpu = len(range(rank, args.frames_total, world))
     if on_gpu:
         torch.cuda.set_device(local)   # before the first HIP call of this rank
     if world > 1:
@@ -325,11 +426,11 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     for _ in range(args.prime + args.warmup):
         load.step()
     load.bits_first = None
-    probe = None
+    probe = hbm = None
     if on_gpu:
         from pseudocylindrical_convolution_amd import PCONV
-        probe = ConvProbe()
-        PCONV.conv_probe = probe
+        probe, hbm = ConvProbe(), ConvProbe()
+        PCONV.conv_probe, PCONV.hbm_probe = probe, hbm
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -337,7 +438,7 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     fence()
     elapsed = time.perf_counter() - t0
     if on_gpu:
-        PCONV.conv_probe = None
+        PCONV.conv_probe = PCONV.hbm_probe = None
     extra = {} if args.no_check else load.check()
 
     from pseudocylindrical_convolution_amd import sharding
@@ -366,7 +467,9 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         frames_total = max(totals["frames"], 1.0)
         config = {"workload": load.describe(), "frames_per_gpu": load.F,
                   "parallelism": "frames sharded, no data-path collective",
-                  "tile_conv_s_per_step": round(conv_s, 4)}
+                  "tile_conv_s_per_step": round(conv_s, 4), "cores_per_rank": cores}
+        if strong:
+            config["frames_total"] = args.frames_total
         if load.name == "codec":
             config["bpp"] = round(totals["bits"] / (frames_total * load.H * load.W), 4)
             if not args.no_check:
@@ -378,9 +481,12 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         out = {
             "metric": metric, "value": round(totals["pixels"] / elapsed / 1e6, 4),
             "unit": "MPix/s", "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roof,
         }
+        if hbm is not None and hbm.records:
+            # the gather / permute kernels of the same timed steps against the HBM roof
+            out["hbm"] = hbm_table(hbm.summarise())
         if load.name == "analysis" or os.environ.get("PCONV_BENCH_TABLE"):
             out["roofline_table"] = table
         if world == 1 and on_gpu and not args.no_cpu_baseline and load.name == "codec":

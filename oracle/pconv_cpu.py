@@ -40,6 +40,37 @@ def lib():
     return _lib
 
 
+def host_cpu_share():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota
+    when there is one (a GPU box shows all 256 host CPUs to a container that owns 16 of them;
+    256 OpenMP threads on a 16-CPU share crawl)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    n = min(n, max(1, int(int(fields[0]) / int(fields[1]))))
+            else:
+                quota = int(fields[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(quota / int(f.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_num_threads(n=None):
+    """threads of the oracle's OpenMP loops (default: the host CPU share, at most 16 -- what a one-GPU
+    box gives its job); returns the count"""
+    n = int(n) if n else max(1, min(host_cpu_share(), 16))
+    lib().orc_set_num_threads(ctypes.c_int(n))
+    return n
+
+
 def set_detmath(on):
     """True: CDF / quantiser tables use the product's published erf/exp polynomials
     (bit-exact comparisons); False: libm, as a stand-in for the reference's CUDA math."""

@@ -42,6 +42,16 @@ typedef int64_t i64;
  * deterministic polynomials the product uses (include/pconv_detmath.h). */
 static int g_detmath = 0;
 void orc_set_detmath(int on) { g_detmath = on; }
+
+/* threads the `#pragma omp parallel for` loops of this file run on (reported by bench.py's cpu_baseline) */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
+#endif
 static float o_erff(float x) { return g_detmath ? pconv_erff(x) : erff(x); }
 static float o_expf(float x) { return g_detmath ? pconv_expf(x) : expf(x); }
 

@@ -90,6 +90,36 @@ def _timed(method, label):
     return run
 
 
+# When set to an object with a `records` list (bench.py), every launch of the HBM-bound gather /
+# permute kernels is bracketed by events on its stream: (kernel, class label, algorithmic bytes of
+# SURVEY 8d for this call, start, end).  None in normal operation.
+hbm_probe = None
+_VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack (SURVEY 8)
+
+
+class _HbmTimed(object):
+    __slots__ = ("probe", "kernel", "label", "nbytes", "stream", "e0")
+
+    def __init__(self, kernel, label, nbytes, device):
+        self.probe = hbm_probe
+        if self.probe is not None:
+            self.kernel, self.label, self.nbytes = kernel, label, float(nbytes)
+            self.stream = torch.cuda.current_stream(device)
+
+    def __enter__(self):
+        if self.probe is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(self.stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self.probe is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.stream)
+            self.probe.records.append((self.kernel, self.label, self.nbytes, self.e0, e1))
+        return False
+
+
 class _Op(object):
     """State shared by all ops: target device and re-used output buffers
     (base_opt.hpp:12-72)."""
@@ -320,7 +350,8 @@ class DtowOp(_Op):
         s = self.stride_
         shape = (n, c // (s * s), h * s, w * s) if self.d2w_ else (n, c * s * s, h // s, w // s)
         out = self._out(0, shape, x)
-        call("pconv_dtow", _ptr(x), _ptr(out), n, c, h, w, s, int(self.d2w_), _stream(x.device))
+        with _HbmTimed("dtow2_kernel" if self.d2w_ else "wtod2_kernel", "Dtow c%d w%d" % (c, w), 8.0 * x.numel(), x.device):
+            call("pconv_dtow", _ptr(x), _ptr(out), n, c, h, w, s, int(self.d2w_), _stream(x.device))
         return [out]
 
     def backward(self, grad):
@@ -441,8 +472,9 @@ class SphereSliceOp(_SphereResample):
         wd, col, coef = self._tables("pconv_host_slice_taps", h, w, x)
         p = self.pad_
         out = self._out(0, (n * self.npart_, c, h // self.npart_ + 2 * p, w + 2 * p), x, zero=p > 0)
-        call("pconv_sphere_slice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
-             self.npart_, p, _stream(x.device))
+        with _HbmTimed("slice_kernel", "SphereSlice w%d" % w, 8.0 * x.numel(), x.device):
+            call("pconv_sphere_slice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+                 self.npart_, p, _stream(x.device))
         return [out]
 
     def backward(self, grad):
@@ -472,8 +504,9 @@ class SphereUsliceOp(_SphereResample):
         n = tn // self.npart_
         wd, col, coef = self._tables("pconv_host_uslice_taps", h * self.npart_, w, x)
         out = self._out(0, (n, c, h * self.npart_, w), x)
-        call("pconv_sphere_uslice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
-             self.npart_, p, _stream(x.device))
+        with _HbmTimed("uslice_kernel", "SphereUslice w%d" % out.shape[3], 8.0 * out.numel(), x.device):
+            call("pconv_sphere_uslice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+                 self.npart_, p, _stream(x.device))
         return [out]
 
     def backward(self, grad):
@@ -507,8 +540,9 @@ class PseudoPadOp(_Op):
         wd = self.ctx_.widths(h, w, x)
         st, sr, col, wgt = self.ctx_.pad_tables(h, w, p, x)
         out = self._out(0, (tn, c, h + 2 * p, w + 2 * p), x)
-        call("pconv_pseudo_pad", _ptr(x), _ptr(out), _ptr(wd), _ptr(st), _ptr(sr), _ptr(col), _ptr(wgt), tn,
-             c, h, w, p, self.npart_, _stream(x.device))
+        with _HbmTimed("pseudo_pad_kernel", "PseudoPad c%d w%d p%d" % (c, w, p), 4.0 * (x.numel() + out.numel()), x.device):
+            call("pconv_pseudo_pad", _ptr(x), _ptr(out), _ptr(wd), _ptr(st), _ptr(sr), _ptr(col), _ptr(wgt), tn,
+                 c, h, w, p, self.npart_, _stream(x.device))
         return [out]
 
     def forward_ring(self, x):
@@ -522,8 +556,9 @@ class PseudoPadOp(_Op):
             return self.forward(x.contiguous())[0]
         wd = self.ctx_.widths(h, w, x)
         st, sr, col, wgt = self.ctx_.pad_tables(h, w, p, x)
-        call("pconv_pseudo_pad_ring", _ptr(buf), _ptr(wd), _ptr(st), _ptr(sr), _ptr(col), _ptr(wgt), tn, c, h, w, p,
-             store, self.npart_, _stream(x.device))
+        with _HbmTimed("pseudo_pad_ring_kernel", "PseudoPad ring c%d w%d p%d" % (c, w, p), 4.0 * tn * c * ((h + 2 * p) * (w + 2 * p) - h * w), x.device):
+            call("pconv_pseudo_pad_ring", _ptr(buf), _ptr(wd), _ptr(st), _ptr(sr), _ptr(col), _ptr(wgt), tn, c, h, w, p,
+                 store, self.npart_, _stream(x.device))
         d = store - p
         return buf if d == 0 else buf[:, :, d:-d, d:-d]
 
@@ -557,8 +592,9 @@ class PseudoFillOp(_Op):
         _require_gpu(x, "PseudoFillOp")
         tn, c, h, w = x.shape
         wd = self.ctx_.widths(h, w, x)
-        call("pconv_pseudo_fill", _ptr(x), _ptr(wd), tn, c, h, w, self.npart_, self.pad_, self.trim_,
-             float(value), _stream(x.device))
+        with _HbmTimed("pseudo_fill_kernel", "PseudoFill c%d w%d" % (c, w), 4.0 * x.numel() * (1.0 - _VALID_FRACTION), x.device):
+            call("pconv_pseudo_fill", _ptr(x), _ptr(wd), tn, c, h, w, self.npart_, self.pad_, self.trim_,
+                 float(value), _stream(x.device))
         return [x]
 
     def forward(self, x):
@@ -657,8 +693,9 @@ class PseudoQuantOp(_Op):
         # reference hands it to autograd as the "gradient" of the module's `count`
         self.count_data_ = self._out("count", (c, self.bin_num_), x)
         self.count_data_.zero_()
-        call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), _ptr(self.count_data_),
-             _ptr(wd), tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
+        with _HbmTimed("quant_kernel", "PseudoQuant c%d w%d" % (x.shape[1], x.shape[3]), 12.0 * x.numel(), x.device):
+            call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), _ptr(self.count_data_),
+                 _ptr(wd), tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
         if train:
             self.iter_ += 1
         return [val, idx] if self.ntop_ > 1 else [val]
@@ -702,8 +739,9 @@ class PseudoDQuantOp(_Op):
         wd = self.ctx_.widths(h, w, x)
         tab = self._out("tab", (self.nchannel_, self.bin_num_), x)
         out = self._out(0, x.shape, x)
-        call("pconv_dquant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(out), _ptr(wd), tn, c, h, w,
-             self.nchannel_, self.bin_num_, self.npart_, _stream(x.device))
+        with _HbmTimed("dquant_kernel", "PseudoDQuant c%d w%d" % (c, w), 8.0 * x.numel(), x.device):
+            call("pconv_dquant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(out), _ptr(wd), tn, c, h, w,
+                 self.nchannel_, self.bin_num_, self.npart_, _stream(x.device))
         return [out]
 
 
@@ -1058,7 +1096,6 @@ def packed_conv_weight(owner, weight, stream):
 # by events on its own stream: (kernel instantiation, class label, algorithmic flops,
 # start, end).  Used by bench.py for the live roofline figures; None in normal operation.
 conv_probe = None
-_VALID_FRACTION = 836.0 / 1024.0  # valid columns / all columns of the tile stack (SURVEY 8)
 
 
 def conv_kernel_name(cout, k, stride, squared=False, cin=0, pixels=0):

@@ -131,7 +131,7 @@ __device__ __forceinline__ void conv_zero_tile(float *outp, const ConvView &vout
 // weight-resident kernels.  Wave (wm, wn) holds MT x NT tiles of 32 couts x 32 pixels:
 // reg r of a tile = cout row (r&3) + 8*(r>>2) + 4*half, pixel column = l31; pixel
 // segment seg = wn*NT + n is row seg/2, 32-column half seg%2 of the workgroup tile.
-template <int MT, int NT, int WN>
+template <int MT, int NT, int WN, int EB = 16>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvEpilogue &ep, const float *inp,
                                               float *outp, const ConvView &vin, const ConvView &vout, int t, int r0,
                                               int c0, int cout0, int cout, int ho, int wo, int wm, int wn, int l31,
@@ -173,55 +173,63 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
     }
     return;
   }
+  static_assert(16 % EB == 0, "epilogue batches are whole fractions of a 32-cout tile");
 #pragma unroll
   for (int m = 0; m < MT; m++) {
-    // the residual values of the whole 32-cout tile are requested first, in one batch: one by one
-    // in front of their use (the compiler cannot move a load above the previous store of `out`)
-    // every one of the 16 x NT round trips was exposed -- 8 % of the kernel on the residual layers
-    float rv[16][NT], q1[16][NT];  // q1: the GDN's own input, or the attention gate (never both)
-    const bool gdn = act == 2 || act == 3;
-    auto batch = [&](float (&dst)[16][NT], const float *src, const ConvView &v) {
+    // the residual values of EB of the 16 cout rows a lane holds of a 32-cout tile are requested first,
+    // in one batch: one by one in front of their use (the compiler cannot move a load above the previous
+    // store of `out`) every one of the 16 x NT round trips was exposed -- 8 % of the kernel on the
+    // residual layers.  EB = 16: the whole tile at once (most in flight); the 1x1 kernels built for
+    // three workgroups per CU take EB = 8 (16 registers fewer).
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
+    for (int rb = 0; rb < 16; rb += EB) {
+      float rv[EB][NT], q1[EB][NT];  // q1: the GDN's own input, or the attention gate (never both)
+      const bool gdn = act == 2 || act == 3;
+      auto batch = [&](float (&dst)[EB][NT], const float *src, const ConvView &v) {
+#pragma unroll
+        for (int rr = 0; rr < EB; rr++) {
+          const int r = rb + rr;
+          const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+          for (int n = 0; n < NT; n++) {
+            const int seg = wn * NT + n;
+            const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+            dst[rr][n] = (co < cout && orow < ho && ocol < wo) ? src[(size_t)co * v.cs + (size_t)orow * v.rs + ocol] : 1.f;
+          }
+        }
+      };
+      if (resp) batch(rv, resp, ep.vres);
+      if (gdn) batch(q1, inp, vin);  // (likewise everything else the way out reads)
+      if (gatep) batch(q1, gatep, ep.vgate);
+#pragma unroll
+      for (int rr = 0; rr < EB; rr++) {
+        const int r = rb + rr;
         const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= cout) continue;
+        const float bco = bias ? bias[co] : 0.f;
+        const float sl = (act == 1) ? slope[co] : 0.f;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
           const int seg = wn * NT + n;
           const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
-          dst[r][n] = (co < cout && orow < ho && ocol < wo) ? src[(size_t)co * v.cs + (size_t)orow * v.rs + ocol] : 1.f;
-        }
-      }
-    };
-    if (resp) batch(rv, resp, ep.vres);
-    if (gdn) batch(q1, inp, vin);  // (likewise everything else the way out reads)
-    if (gatep) batch(q1, gatep, ep.vgate);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= cout) continue;
-      const float bco = bias ? bias[co] : 0.f;
-      const float sl = (act == 1) ? slope[co] : 0.f;
-#pragma unroll
-      for (int n = 0; n < NT; n++) {
-        const int seg = wn * NT + n;
-        const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
-        if (orow < ho && ocol < wo) {
-          const size_t oi = (size_t)co * vout.cs + (size_t)orow * vout.rs + ocol;
-          float v = acc[m][n][r] + bco;
-          if (act == 1) {
-            if (v < 0) v = v * sl;
-          } else if (gdn) {
-            // 1x1, stride 1: input and output share their geometry
-            const float xv = q1[r][n];
-            const float nrm = sqrtf(v);
-            v = act == 2 ? xv / nrm : xv * nrm;
-          } else if (act == 4) {
-            v = 1.f / (1.f + expf(-v));
+          if (orow < ho && ocol < wo) {
+            const size_t oi = (size_t)co * vout.cs + (size_t)orow * vout.rs + ocol;
+            float v = acc[m][n][r] + bco;
+            if (act == 1) {
+              if (v < 0) v = v * sl;
+            } else if (gdn) {
+              // 1x1, stride 1: input and output share their geometry
+              const float xv = q1[rr][n];
+              const float nrm = sqrtf(v);
+              v = act == 2 ? xv / nrm : xv * nrm;
+            } else if (act == 4) {
+              v = 1.f / (1.f + expf(-v));
+            }
+            if (gatep) v = q1[rr][n] * v;
+            if (resp) v = rv[rr][n] + v;
+            if (ocol >= trim_at) v = 0.f;
+            outp[oi] = v;
           }
-          if (gatep) v = q1[r][n] * v;
-          if (resp) v = rv[r][n] + v;
-          if (ocol >= trim_at) v = 0.f;
-          outp[oi] = v;
         }
       }
     }
@@ -368,8 +376,17 @@ __device__ __forceinline__ void conv_chunk_prologue(float (&a)[kAhead + 1][C::MT
   }
 }
 
+// 1x1 layers (and the GDN contraction): waves per SIMD the kernel is compiled for and cout rows per
+// epilogue batch (tuning knobs; the 3x3 kernels keep 4 waves per SIMD = two 8-wave workgroups per CU)
+#ifndef PCONV_1X1_WAVES_EU
+#define PCONV_1X1_WAVES_EU 2
+#endif
+#ifndef PCONV_1X1_EPI_ROWS
+#define PCONV_1X1_EPI_ROWS 16
+#endif
+
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
+__global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_WAVES_EU : 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
     int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, int xcd_group, ConvView vin,
     ConvView vout, ConvEpilogue ep) {
@@ -512,7 +529,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(
 #ifdef PCONV_ABL_NOEPI
   if (cin == -12345)
 #endif
-  conv_epilogue<MT, NT, WN>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half);
+  conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,
+                                                                                      cout, ho, wo, wm, wn, l31, half);
 }
 
 // ---- weight-resident, register-blocked 1x1 convolution ---------------------------------

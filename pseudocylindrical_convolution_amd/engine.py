@@ -152,13 +152,54 @@ class CodecEngine(object):
             self._engines[key].bind(ent)
         return self._engines[key]
 
+    # Transform stages below 1/4 scale do not fill the chip on one frame (a 3x3 192->192 launch at
+    # 1/8 scale has 8 x fewer workgroups than at 1/2 scale): blocks [0, ANALYSIS_SPLIT) of EncoderV2.net
+    # run frame by frame (their activations are GBs at 4096x2048), the rest -- 1/8 scale and below -- on
+    # all frames of the call at once; likewise the first SYNTHESIS_SPLIT blocks of DecoderV2.net.  Every
+    # output is the same fmaf chain either way (bit-identical).  0 = whole transform frame by frame.
+    ANALYSIS_SPLIT = int(os.environ.get("PCONV_ANALYSIS_SPLIT", "6"))
+    SYNTHESIS_SPLIT = int(os.environ.get("PCONV_SYNTHESIS_SPLIT", "5"))
+
+    @staticmethod
+    def _frame_of(x, i, tiles):
+        """tile-batch rows of frame i of a batched activation; keeps the padded-buffer tag so that
+        the consumer's PseudoPad still only fills the ring"""
+        y = x[i * tiles:(i + 1) * tiles]
+        ring = getattr(x, "_pconv_ring", None)
+        if ring is not None:
+            y._pconv_ring = (ring[0][i * tiles:(i + 1) * tiles], ring[1])
+        return y
+
     @torch.no_grad()
     def symbols(self, frames):
-        """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero.
-        The analysis transform runs frame by frame (its activations are GBs at
-        4096x2048); only the small symbol tensors are batched."""
-        per_frame = [self.enc.ent.fill(self.enc.symbols(frames[i:i + 1])).clone() for i in range(frames.shape[0])]
-        return per_frame[0] if len(per_frame) == 1 else torch.cat(per_frame, 0)
+        """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero."""
+        enc, n, k = self.enc, frames.shape[0], self.ANALYSIS_SPLIT
+        if n == 1 or k <= 0 or not hasattr(enc.encoder, "forward_range"):
+            per_frame = [enc.ent.fill(enc.symbols(frames[i:i + 1])).clone() for i in range(n)]
+            return per_frame[0] if len(per_frame) == 1 else torch.cat(per_frame, 0)
+        mids = [enc.encoder.forward_range(enc.slice(frames[i:i + 1]), 0, k) for i in range(n)]
+        code = enc.encoder.forward_range(torch.cat(mids, 0), k, len(enc.encoder.net))
+        del mids
+        _, code_i = enc.quant(code)
+        return enc.ent.fill(enc.dtw(enc.ext(code_i))).clone()
+
+    @torch.no_grad()
+    def reconstruct(self, sym, n):
+        """decoded symbols of n frames (n*16, valid_dim/4, 2h, 2w) -> (n, 3, H, W)"""
+        dec, tiles, k = self.dec, self.dec.npart, self.SYNTHESIS_SPLIT
+        if n == 1 or k <= 0 or not hasattr(dec.decoder, "forward_range"):
+            out = [dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(n)]
+            return out[0] if n == 1 else torch.cat(out, 0)
+        code_ext = dec.quant(dec.wtd(sym))
+        code_f = torch.zeros((code_ext.shape[0], dec.code_channels) + tuple(code_ext.shape[2:]), dtype=code_ext.dtype,
+                             device=code_ext.device)
+        code_f[:, :dec.valid_dim] = code_ext
+        mid = dec.decoder.forward_range(code_f.contiguous(), 0, k)
+        out = []
+        for i in range(n):
+            tx = dec.decoder.forward_range(self._frame_of(mid, i, tiles), k, len(dec.decoder.net))
+            out.append(dec.clip(dec.uslice(tx)).clone())
+        return torch.cat(out, 0)
 
     # frames entropy-coded per pipeline stage of encode(): the stage's tables are arithmetic-coded
     # on the CPU while the GPU runs the analysis transform of the following frames
@@ -172,11 +213,19 @@ class CodecEngine(object):
         engine: the coder reads the engine's pinned buffers until encode_end)."""
         n = frames.shape[0]
         chunk = self.ENCODE_CHUNK if n > self.ENCODE_CHUNK else n
+        tiles = self.enc.ent.npart
+        # with the split transform the symbols of ALL frames come out of one batched tail: the chunks
+        # then only pipeline the entropy stage (GPU tables of chunk k+1 beside the CPU coding of chunk k)
+        batched = self.ANALYSIS_SPLIT > 0 and n > 1 and hasattr(self.enc.encoder, "forward_range")
+        sym_all = self.symbols(frames).contiguous() if batched else None
         pending, out = [], []
         try:
             for k, lo in enumerate(range(0, n, chunk)):
-                sym = self.symbols(frames[lo:lo + chunk]).contiguous()
-                eng = self._engine("enc", sym.shape[2], sym.shape[3], sym.shape[0] // self.enc.ent.npart, slot=k)
+                if batched:
+                    sym = sym_all[lo * tiles:(lo + chunk) * tiles]
+                else:
+                    sym = self.symbols(frames[lo:lo + chunk]).contiguous()
+                eng = self._engine("enc", sym.shape[2], sym.shape[3], sym.shape[0] // tiles, slot=k)
                 eng.encode_begin(sym)
                 pending.append(eng)
         except BaseException:
@@ -208,8 +257,7 @@ class CodecEngine(object):
         chunk = self.DECODE_CHUNK
         if chunk <= 0 or n <= chunk:
             sym = self._engine("dec", 2 * h, 2 * w, n).decode(streams)
-            out = [self.dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(n)]
-            return out[0] if n == 1 else torch.cat(out, 0)
+            return self.reconstruct(sym, n)
         chunks = [streams[i:i + chunk] for i in range(0, n, chunk)]
         side = torch.cuda.Stream(device=self.device)
         box = {}
@@ -234,7 +282,7 @@ class CodecEngine(object):
             if k + 1 < len(chunks):
                 worker = threading.Thread(target=run, args=(k + 1,))
                 worker.start()
-            out += [self.dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(len(chunks[k]))]
+            out.append(self.reconstruct(sym, len(chunks[k])))
             if worker is not None:
                 worker.join()
         return torch.cat(out, 0)

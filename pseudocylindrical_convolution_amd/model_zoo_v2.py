@@ -237,9 +237,17 @@ class EncoderV2(nn.Module):
         backend.watch_state_dict(self)  # packed conv slabs / GDN parameters follow a reload
 
     def forward(self, x):
-        for m in self.net[:-1]:
+        return self.forward_range(x, 0, len(self.net))
+
+    def forward_range(self, x, lo, hi):
+        """blocks net[lo:hi] (the whole transform: 0, len(net)).  Lets a caller run the full-size
+        stages frame by frame and the small-scale tail on several frames at once (engine.CodecEngine)."""
+        last = len(self.net) - 1
+        for m in self.net[lo:min(hi, last)]:
             x = m(x)
-        return self.net[-1](x, (self.ctx, x.shape[3]), sigmoid=True, trim=self.trim)  # self.act fused
+        if hi > last:
+            x = self.net[-1](x, (self.ctx, x.shape[3]), sigmoid=True, trim=self.trim)  # self.act fused
+        return x
 
 
 class ResidualBlockUp(nn.Module):
@@ -298,11 +306,19 @@ class DecoderV2(nn.Module):
         backend.watch_state_dict(self)
 
     def forward(self, x):
+        return self.forward_range(x, 0, len(self.net))
+
+    def forward_range(self, x, lo, hi):
+        """blocks net[lo:hi] (see EncoderV2.forward_range); the final 3x3 conv and its
+        depth-to-width (net[-2], net[-1]) always run together"""
         mods = list(self.net)
-        for m in mods[:-2]:  # the blocks and the last pad
+        body = len(mods) - 2
+        for m in mods[lo:min(hi, body)]:  # the blocks and the last pad
             x = m(x)
-        # 3x3 conv to 12 channels + the depth-to-width that makes them 3 at full size
-        return mods[-2](x, (self.ctx, x.shape[3] - 2), d2w=mods[-1])
+        if hi > body:
+            # 3x3 conv to 12 channels + the depth-to-width that makes them 3 at full size
+            x = mods[-2](x, (self.ctx, x.shape[3] - 2), d2w=mods[-1])
+        return x
 
 
 # --------------------------------------------------------------------------

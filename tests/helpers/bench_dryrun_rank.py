@@ -37,6 +37,9 @@ class OracleToyWorkload(object):
         self.syms = [torch.randint(0, 8, (16, 4, 1, 64), generator=torch.Generator().manual_seed(100 + rank * self.F + i)).float()
                      for i in range(self.F)]
         self.dir = os.environ["PCONV_DRYRUN_DIR"]
+        import json
+        with open(os.path.join(self.dir, "affinity_r%d.json" % rank), "w") as f:   # what bench.pin_rank left this rank
+            json.dump({"cpus": sorted(os.sched_getaffinity(0)), "frames": self.F, "torch_threads": torch.get_num_threads()}, f)
         self.bits, self.bits_first, self.back = 0, None, None
 
     def step(self):

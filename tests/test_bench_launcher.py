@@ -13,11 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "helpers", "bench_dryrun_rank.py")
 
 
-def _run(nproc, tmp_path):
+def _run(nproc, tmp_path, frames=("--frames-per-gpu", "2")):
     code = ("import sys; sys.path.insert(0, %r); import bench; "
             "sys.exit(bench.launch_ranks(%d, ['--gpus', '%d', '--steps', '2', '--warmup', '1', '--prime', '0', "
-            "'--frames-per-gpu', '2'], script=%r, env={'PCONV_DRYRUN_DIR': %r}))"
-            % (ROOT, nproc, nproc, WORKER, str(tmp_path)))
+            "%r, %r], script=%r, env={'PCONV_DRYRUN_DIR': %r}))"
+            % (ROOT, nproc, nproc, frames[0], frames[1], WORKER, str(tmp_path)))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -35,6 +35,37 @@ def test_launcher_starts_two_ranks_and_reduces(tmp_path):
     pixels_per_rank_step = 2 * 256 * 1024
     assert abs(two["value"] * 1e6 * two["ms_per_step"] * 1e-3 - 2 * pixels_per_rank_step) / (2 * pixels_per_rank_step) < 0.01
     assert two["config"]["bpp"] > 0
+    # every rank kept its own slice of the host cores (bench.pin_rank), before creating any thread
+    allowed = sorted(os.sched_getaffinity(0))
+    kept = [json.load(open(os.path.join(str(tmp_path), "affinity_r%d.json" % r))) for r in range(2)]
+    if len(allowed) >= 2:
+        assert not set(kept[0]["cpus"]) & set(kept[1]["cpus"])
+        assert sorted(kept[0]["cpus"] + kept[1]["cpus"]) == allowed
+        assert two["config"]["cores_per_rank"] == len(kept[0]["cpus"]) == kept[0]["torch_threads"]
+
+
+@pytest.mark.timeout(1200)
+def test_strong_scaling_mode_splits_a_fixed_batch(tmp_path):
+    """--frames-total F (BASELINE config #5: batch 64 over N GPUs): rank r takes frames r::world"""
+    two = _run(2, tmp_path, ("--frames-total", "5"))
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["frames_total"] == 5
+    kept = [json.load(open(os.path.join(str(tmp_path), "affinity_r%d.json" % r))) for r in range(2)]
+    assert [k["frames"] for k in kept] == [3, 2]
+    pixels_step = 5 * 256 * 1024
+    assert abs(two["value"] * 1e6 * two["ms_per_step"] * 1e-3 - pixels_step) / pixels_step < 0.01
+
+
+def test_rank_cpu_slices_are_disjoint_and_cover():
+    sys.path.insert(0, ROOT)
+    import bench
+    for ncpu, world in ((128, 8), (16, 8), (10, 4), (8, 8), (3, 8)):
+        allowed = list(range(100, 100 + ncpu))
+        parts = [bench.rank_cpus(r, world, allowed) for r in range(world)]
+        if ncpu >= world:
+            assert sorted(c for p in parts for c in p) == allowed
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        else:
+            assert all(p == allowed for p in parts)
 
 
 def test_main_becomes_launcher_only_without_world_size(monkeypatch):

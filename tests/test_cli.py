@@ -21,13 +21,13 @@ def _write_png(path, H, W, seed):
     Image.fromarray((img.clip(0, 1) * 255).astype(np.uint8)).save(path)
 
 
-def _models(tmp_path):
+def _models(tmp_path, device):
     """demo/ssim/4_56_{encoder,decoder,ent}.pt (model-idx 3 of the --ssim list) from a seeded random
     training graph, and the two files check_models() looks for"""
     from pseudocylindrical_convolution_amd import export, model_zoo_v2 as zoo
     torch.manual_seed(77)
     net = zoo.CMPNetV2MF(56, 192, 192, 16, 8, True, False, 0)
-    state = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    state = {k: v.detach().to(device) for k, v in net.state_dict().items()}   # export masks weights on the op backend's device
     export.export_codec(state, 56, str(tmp_path / "demo" / "ssim"), "4_56")
     export.export_codec(state, 56, str(tmp_path / "demo" / "ssim"), "1_56")
     export.export_codec(state, 56, str(tmp_path / "demo" / "mse"), "1_56")
@@ -36,7 +36,7 @@ def _models(tmp_path):
 def _drive(tmp_path, monkeypatch, capsys, sizes, device):
     from pseudocylindrical_convolution_amd import pseudo_codec as PC, container
     monkeypatch.chdir(tmp_path)
-    _models(tmp_path)
+    _models(tmp_path, device)
     common = ["--ssim", "--model-idx", "3"]
     for k, (H, W) in enumerate(sizes):
         src, raw, boxed = "img%d.png" % k, "code%d.bin" % k, "code%d.pcv" % k

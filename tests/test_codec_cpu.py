@@ -121,3 +121,24 @@ def test_quantiser_level_update_matches_oracle_semantics(oracle_backend):
         op.forward(x, w, cnt, True)
     assert torch.allclose(w[:, 4:], torch.full((4, 4), -2.0 - float(torch.log(torch.tensor(4.0)))))
     assert torch.allclose(cnt[:, :5], torch.full((4, 5), 0.9))
+
+
+def test_split_transforms_equal_frame_by_frame(oracle_backend):
+    """CodecEngine runs the small-scale tail of the analysis transform (and the head of the synthesis
+    transform) on all frames of a call at once: same bits as the whole transform frame by frame"""
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = _codec()
+    eng = CodecEngine(56, 0, enc, dec)
+    assert 0 < eng.ANALYSIS_SPLIT < len(enc.encoder.net) and 0 < eng.SYNTHESIS_SPLIT < len(dec.decoder.net) - 2
+    x = torch.rand(3, 3, 256, 512, generator=torch.Generator().manual_seed(9))
+    one_by_one = torch.cat([enc.ent.fill(enc.symbols(x[i:i + 1])).clone() for i in range(3)], 0)
+    sym = eng.symbols(x)
+    assert torch.equal(sym, one_by_one)
+    rec = eng.reconstruct(sym, 3)
+    for i in range(3):
+        assert torch.equal(rec[i:i + 1], dec.reconstruct(sym[i * 16:(i + 1) * 16]))
+    # every split point gives the same transform
+    t = enc.slice(x[:1])
+    whole = enc.encoder(t).clone()
+    for k in (1, 4, 9):
+        assert torch.equal(enc.encoder.forward_range(enc.encoder.forward_range(t, 0, k), k, 10), whole)

@@ -1,3 +1,10 @@
+// (r3: two kernels.  `ac_decode_kernel` is round 2's: it loads every CDF row and every stream byte from
+// GLOBAL memory inside the serial loop, so its 377 ns/symbol is one memory round trip per symbol, not the
+// decoder.  `ac_decode_lds_kernel` is the decoder itself: the rows of a step are known before its first
+// symbol is decoded, so the whole step's rows and its byte window are copied to LDS by all lanes first
+// (coalesced), the row of symbol i+1 is read while symbol i is decoded, and nothing in the dependent
+// chain touches global memory.)
+//
 // How fast can ONE wave of the GPU run the codec's arithmetic decoder?  ("decoder on the
 // device".)  The same decoder as csrc/coder.cpp -- 32-bit state, 8-symbol rows with total 65536, clz
 // renormalisation, the symbol found as the number of thresholds (row[k] * range >> 16) <= offset -- written
@@ -72,6 +79,95 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const int32_t *__restrict
     if (lane == 0) out[i] = sym;
   }
 }
+
+// ---- the same decoder with the step's rows and byte window resident in LDS -------------------------
+constexpr int kStep = 1920;          // symbols of one wavefront step of a 4096x2048 frame (one frame group)
+constexpr int kWindow = 2 * kStep;   // bytes the step may consume: 16 bits per symbol is the coder's worst case
+
+struct LdsBitReader {  // big-endian bit stream over an LDS window, 64-bit accumulator
+  const uint8_t *w;    // LDS
+  int pos, have;
+  uint64_t acc;
+  __device__ void init(const uint8_t *window) { w = window; pos = 0; have = 0; acc = 0; }
+  __device__ uint32_t get(int n) {  // 0 < n <= 32
+    if (have < n) {
+      // refill 4 bytes at a time from LDS (byte-aligned positions: assemble from single bytes)
+      while (have <= 32) {
+        const uint32_t four = ((uint32_t)w[pos] << 24) | ((uint32_t)w[pos + 1] << 16) | ((uint32_t)w[pos + 2] << 8) | w[pos + 3];
+        acc |= (uint64_t)four << (32 - have);
+        pos += 4;
+        have += 32;
+      }
+    }
+    const uint32_t v = (uint32_t)(acc >> (64 - n));
+    acc <<= n;
+    have -= n;
+    return v;
+  }
+};
+
+__global__ __launch_bounds__(64) void ac_decode_lds_kernel(const int32_t *__restrict__ rows, const uint8_t *__restrict__ bytes,
+                                                           size_t nbytes, int32_t *__restrict__ out, int n) {
+  __shared__ int32_t row_s[kStep * 9];
+  __shared__ uint8_t win_s[kWindow + 16];
+  __shared__ int32_t sym_s[kStep];
+  const int lane = threadIdx.x;
+  size_t consumed_bits = 0;  // stream position at the start of the step
+  uint32_t low = 0, high = 0xffffffffu, code = 0;
+  bool primed = false;
+  for (int s0 = 0; s0 < n; s0 += kStep) {
+    const int len = n - s0 < kStep ? n - s0 : kStep;
+    // all lanes: this step's rows and byte window -> LDS (what a fused table kernel would leave there)
+    for (int e = lane; e < len * 9; e += 64) row_s[e] = rows[(size_t)s0 * 9 + e];
+    const size_t byte0 = consumed_bits >> 3;
+    for (int e = lane; e < kWindow + 16; e += 64) win_s[e] = byte0 + e < nbytes ? bytes[byte0 + e] : 0;
+    __syncthreads();
+    LdsBitReader br;
+    br.init(win_s);
+    if (consumed_bits & 7) (void)br.get((int)(consumed_bits & 7));
+    size_t used = consumed_bits & 7;
+    if (!primed) {
+      code = br.get(32);
+      used += 32;
+      primed = true;
+    }
+    uint32_t t = (uint32_t)row_s[lane < 9 ? lane : 8];
+    for (int i = 0; i < len; i++) {
+      // the next symbol's row is requested before this symbol's dependent chain starts
+      const uint32_t tnext = (uint32_t)row_s[(i + 1 < len ? i + 1 : i) * 9 + (lane < 9 ? lane : 8)];
+      const uint64_t range = (uint64_t)high - low + 1;
+      const uint32_t offset = code - low;
+      const uint64_t thr = ((uint64_t)t * range) >> 16;
+      const unsigned long long le = __ballot(lane >= 1 && lane < 8 && thr <= offset);
+      const int sym = __popcll(le);
+      const uint64_t lo_thr = __shfl(thr, sym), hi_thr = __shfl(thr, sym + 1);
+      const uint32_t base = low;
+      low = base + (uint32_t)lo_thr;
+      high = base + (uint32_t)(hi_thr - 1);
+      const int agree = __clz((int)(low ^ high));
+      if (agree > 0) {
+        code = (agree == 32 ? 0u : code << agree) | br.get(agree);
+        used += agree;
+        low = agree == 32 ? 0u : low << agree;
+        high = agree == 32 ? 0xffffffffu : (high << agree) | ((1u << agree) - 1);
+      }
+      const uint32_t pattern = (low & ~high & 0x7fffffffu) << 1;
+      const int squeeze = __clz((int)~pattern);
+      if (squeeze > 0) {
+        code = (code & kTop) | ((code << squeeze) & 0x7fffffffu) | br.get(squeeze);
+        used += squeeze;
+        low = (low << squeeze) & 0x7fffffffu;
+        high = ((high << squeeze) & 0x7fffffffu) | kTop | ((1u << squeeze) - 1);
+      }
+      if (lane == 0) sym_s[i] = sym;
+      t = tnext;
+    }
+    consumed_bits = (consumed_bits & ~(size_t)7) + used;
+    __syncthreads();
+    for (int e = lane; e < len; e += 64) out[s0 + e] = sym_s[e];  // (a fused scatter kernel would read them from LDS)
+    __syncthreads();
+  }
+}
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -141,22 +237,35 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  float best = 1e9f;
-  for (int rep = 0; rep < 3; rep++) {
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(ac_decode_kernel, dim3(1), dim3(64), 0, 0, rows_d, bytes_d, nbytes, out_d, n);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms;
-    hipEventElapsedTime(&ms, e0, e1);
-    best = ms < best ? ms : best;
-  }
   std::vector<int32_t> gpu(n);
-  hipMemcpy(gpu.data(), out_d, (size_t)n * 4, hipMemcpyDeviceToHost);
-  bad = 0;
-  for (int i = 0; i < n; i++) bad += gpu[i] != sym[i];
-  printf("device decoder (one wave): %.1f ns/symbol, %d mismatches\n", best * 1e6 / n, bad);
-  printf("a decode step of one 4096x2048 frame has ~1920 symbols: %.1f us on the device, %.1f us on a host core\n",
-         best * 1e6 / n * 1920 / 1e3, best_cpu / n * 1e9 * 1920 / 1e3);
-  return bad != 0;
+  int failed = 0;
+  float per_kernel[2] = {0, 0};
+  for (int which = 0; which < 2; which++) {
+    float best = 1e9f;
+    hipMemset(out_d, 0xff, (size_t)n * 4);
+    for (int rep = 0; rep < 3; rep++) {
+      hipEventRecord(e0, 0);
+      if (which == 0)
+        hipLaunchKernelGGL(ac_decode_kernel, dim3(1), dim3(64), 0, 0, rows_d, bytes_d, nbytes, out_d, n);
+      else
+        hipLaunchKernelGGL(ac_decode_lds_kernel, dim3(1), dim3(64), 0, 0, rows_d, bytes_d, nbytes, out_d, n);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    hipMemcpy(gpu.data(), out_d, (size_t)n * 4, hipMemcpyDeviceToHost);
+    bad = 0;
+    for (int i = 0; i < n; i++) bad += gpu[i] != sym[i];
+    failed += bad != 0;
+    per_kernel[which] = best * 1e6f / n;
+    printf("device decoder, one wave, %s: %.1f ns/symbol, %d mismatches\n",
+           which == 0 ? "rows and bytes loaded from GLOBAL memory inside the serial loop (round 2's probe)"
+                      : "step's rows and byte window resident in LDS, next row read ahead",
+           per_kernel[which], bad);
+  }
+  printf("a decode step of one 4096x2048 frame has ~1920 symbols: %.1f us on the device (LDS-resident), %.1f us on a host core\n",
+         per_kernel[1] * 1920 / 1e3, best_cpu / n * 1e9 * 1920 / 1e3);
+  return failed != 0;
 }
