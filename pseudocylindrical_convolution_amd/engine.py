@@ -152,13 +152,15 @@ class CodecEngine(object):
             self._engines[key].bind(ent)
         return self._engines[key]
 
-    # Transform stages below 1/4 scale do not fill the chip on one frame (a 3x3 192->192 launch at
-    # 1/8 scale has 8 x fewer workgroups than at 1/2 scale): blocks [0, ANALYSIS_SPLIT) of EncoderV2.net
-    # run frame by frame (their activations are GBs at 4096x2048), the rest -- 1/8 scale and below -- on
-    # all frames of the call at once; likewise the first SYNTHESIS_SPLIT blocks of DecoderV2.net.  Every
-    # output is the same fmaf chain either way (bit-identical).  0 = whole transform frame by frame.
-    ANALYSIS_SPLIT = int(os.environ.get("PCONV_ANALYSIS_SPLIT", "6"))
-    SYNTHESIS_SPLIT = int(os.environ.get("PCONV_SYNTHESIS_SPLIT", "5"))
+    # Transform stages from 1/4 scale down do not fill the chip on one frame (a 3x3 192->192 launch at
+    # 1/8 scale has 16 x fewer workgroups than at 1/2 scale; at 1/4 scale the last of its 6.5 rounds of
+    # workgroups is half empty): blocks [0, ANALYSIS_SPLIT) of EncoderV2.net run frame by frame (their
+    # activations are GBs at 4096x2048), the rest -- 1/4 scale and below -- on all frames of the call at
+    # once; likewise the first SYNTHESIS_SPLIT blocks of DecoderV2.net.  Every output is the same fmaf
+    # chain either way (bit-identical).  0 = whole transform frame by frame.  Measured (8 frames,
+    # profiles/round3_split_transforms.txt): 0/0 52.6, 6/5 54.0, 3/8 54.5 MPix/s.
+    ANALYSIS_SPLIT = int(os.environ.get("PCONV_ANALYSIS_SPLIT", "3"))
+    SYNTHESIS_SPLIT = int(os.environ.get("PCONV_SYNTHESIS_SPLIT", "8"))
 
     @staticmethod
     def _frame_of(x, i, tiles):
@@ -170,6 +172,21 @@ class CodecEngine(object):
             y._pconv_ring = (ring[0][i * tiles:(i + 1) * tiles], ring[1])
         return y
 
+    @staticmethod
+    def _batch_buffer(like, n):
+        """(n * tiles, C, h, w) tensor for n frames' worth of `like`; when `like` lives inside a padded
+        buffer (its producer wrote it there for the consumer's PseudoPad) so does the batch, so that the
+        first batched block still only fills the ring instead of copying the tensor"""
+        tn, c, h, w = like.shape
+        ring = getattr(like, "_pconv_ring", None)
+        if ring is None:
+            return torch.empty((n * tn, c, h, w), dtype=like.dtype, device=like.device)
+        r = ring[1]
+        buf = torch.empty((n * tn, c, h + 2 * r, w + 2 * r), dtype=like.dtype, device=like.device)
+        out = buf[:, :, r:-r, r:-r]
+        out._pconv_ring = (buf, r)
+        return out
+
     @torch.no_grad()
     def symbols(self, frames):
         """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero."""
@@ -177,9 +194,15 @@ class CodecEngine(object):
         if n == 1 or k <= 0 or not hasattr(enc.encoder, "forward_range"):
             per_frame = [enc.ent.fill(enc.symbols(frames[i:i + 1])).clone() for i in range(n)]
             return per_frame[0] if len(per_frame) == 1 else torch.cat(per_frame, 0)
-        mids = [enc.encoder.forward_range(enc.slice(frames[i:i + 1]), 0, k) for i in range(n)]
-        code = enc.encoder.forward_range(torch.cat(mids, 0), k, len(enc.encoder.net))
-        del mids
+        mid = None
+        for i in range(n):
+            m = enc.encoder.forward_range(enc.slice(frames[i:i + 1]), 0, k)
+            if mid is None:
+                mid = self._batch_buffer(m, n)
+            mid[i * m.shape[0]:(i + 1) * m.shape[0]].copy_(m)
+            del m
+        code = enc.encoder.forward_range(mid, k, len(enc.encoder.net))
+        del mid
         _, code_i = enc.quant(code)
         return enc.ent.fill(enc.dtw(enc.ext(code_i))).clone()
 
@@ -203,7 +226,7 @@ class CodecEngine(object):
 
     # frames entropy-coded per pipeline stage of encode(): the stage's tables are arithmetic-coded
     # on the CPU while the GPU runs the analysis transform of the following frames
-    ENCODE_CHUNK = 2
+    ENCODE_CHUNK = int(os.environ.get("PCONV_ENCODE_CHUNK", "2"))
 
     @torch.no_grad()
     def encode(self, frames):

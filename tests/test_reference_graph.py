@@ -104,6 +104,19 @@ def test_hip_transforms_match_the_reference_graph_fixture(which, size, hip_backe
     exp = expected(which, size, 0)
     assert list(out.shape) == [int(v) for v in exp["shape"]]
     got, want = kept(out), torch.from_numpy(exp["values"])
+    if which == "DecoderV2":
+        # the synthesis transform ends without a PseudoFill (model_zoo_v2.py:205-211): beyond a tile's
+        # valid width the reference graph leaves whatever the last convolution makes of zeros, the HIP
+        # path writes zeros without computing them -- SphereUslice never reads those columns.  Compare
+        # the valid columns.
+        from pseudocylindrical_convolution_amd.PCONV_operator import set_weight
+        tn, c, h, w = out.shape
+        widths = torch.tensor([int(v / 64.0 * w + 0.5) for v in set_weight(16, True)])
+        idx = torch.arange(out.numel()) if out.numel() <= 65536 else torch.arange(0, out.numel(), GRAPH_STRIDE)
+        live = (idx % w) < widths[(idx // (c * h * w)) % 16]
+        assert live.float().mean().item() > 0.7
+        assert ((got - want).abs() * live).max().item() <= 1e-4
+        return
     assert (got - want).abs().max().item() <= 1e-4
     d = out.detach().cpu().reshape(-1).double()
     assert abs(d.sum().item() - exp["sum"].item()) <= 1e-4 * max(1.0, exp["abs_sum"].item())
