@@ -270,6 +270,22 @@ int pconv_conv2d(const float *in, const float *packed_w, const float *bias, floa
                  const float *residual, const float *gate, int trim, int d2w,
                  const long long *views, void *stream);
 
+/* The same convolution for k = 3, stride 1 by Winograd F(2x2, 3x3) on the fp32 matrix cores
+ * (csrc/wino.hip): 4 instead of 9 multiply-adds per input channel, output channel and pixel -- the
+ * algorithm cuDNN runs the reference's fp32 3x3 nn.Conv2d layers with (model_zoo_v2.py:41-45,83-86,
+ * 158-164).  Results differ from pconv_conv2d's fmaf chain by rounding (~1e-6 relative).
+ * packed_u from pconv_wino_pack_weight (pconv_wino_packed_size floats).  Arguments as pconv_conv2d
+ * without k / stride / gate; act 0 or 1; views: 9 strides (in, out, residual) or NULL.  Takes layers
+ * with pconv_wino_supported(...) != 0 (even output size, cin >= 8, cout >= 32); rows of out /
+ * residual must start on 8-byte boundaries. */
+long long pconv_wino_packed_size(int cout, int cin);
+int pconv_wino_pack_weight(const float *w, float *packed, int cout, int cin, void *stream);
+int pconv_wino_supported(int cin, int h, int w, int cout, int d2w);
+int pconv_conv3x3_wino(const float *in, const float *packed_u, const float *bias, float *out,
+                       int tn, int cin, int h, int w, int cout, int act, const float *slope,
+                       const int32_t *col_limit, int npart, const float *residual, int trim,
+                       int d2w, const long long *views, void *stream);
+
 /* PseudoGDNV2.forward (PseudoContextV2.py:133-216) in one launch on the same
  * kernel: out = in / sqrt(beta + gamma * in^2) over channels (inverse: in * sqrt),
  * zeros from each tile's col_limit on (the reference's mask).  in, out

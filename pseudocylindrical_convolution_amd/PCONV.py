@@ -1092,6 +1092,32 @@ def packed_conv_weight(owner, weight, stream):
     return packed
 
 
+def packed_wino_weight(owner, weight, stream):
+    """U = G g Gt of a 3x3 weight in the layout of pconv_conv3x3_wino, cached like packed_conv_weight"""
+    from .PCONV_operator import backend
+    key = (weight.data_ptr(), weight._version, weight.device, backend.param_epoch())
+    cached = getattr(owner, "_pconv_packed_wino", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    size = int(_native.hip_lib().pconv_wino_packed_size(cout, cin))
+    packed = torch.empty(size, dtype=torch.float32, device=weight.device)
+    call("pconv_wino_pack_weight", _ptr(weight.detach().contiguous()), _ptr(packed), cout, cin, stream)
+    owner._pconv_packed_wino = (key, packed)
+    return packed
+
+
+def conv3x3_mode():
+    """'wino' (default) or 'direct' (PCONV_CONV3X3=direct): which kernel takes the 3x3 stride-1 layers"""
+    import os
+    return "direct" if os.environ.get("PCONV_CONV3X3", "wino")[0] == "d" else "wino"
+
+
+def _aligned8(t):
+    """rows of a (tile, channel, row, col) tensor start on 8-byte boundaries (float2 / float4 stores)"""
+    return t.data_ptr() % 8 == 0 and t.stride(0) % 2 == 0 and t.stride(1) % 2 == 0 and t.stride(2) % 2 == 0
+
+
 # when set to an object with a `records` list, every tile-conv / GDN launch is bracketed
 # by events on its own stream: (kernel instantiation, class label, algorithmic flops,
 # start, end).  Used by bench.py for the live roofline figures; None in normal operation.
@@ -1195,27 +1221,39 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     if cin != cin_w or k != k2:
         raise PconvError("tile_conv2d: weight %s does not fit input %s" % (tuple(weight.shape), tuple(x.shape)))
     stream = _stream(x.device)
-    packed = packed_conv_weight(owner, weight, stream)
     ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
     out = _ring_output((tn, cout // 4, 2 * ho, 2 * wo) if d2w else (tn, cout, ho, wo), ring, x)
-    probe = conv_probe
-    if probe is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(x.device))
     if sigmoid and slope is not None:
         raise PconvError("tile_conv2d: PReLU and sigmoid are exclusive")
     if d2w and (gate is not None or residual is not None or trim or sigmoid or cout % 4):
         raise PconvError("tile_conv2d: d2w takes no sigmoid / gate / residual / trim and needs cout % 4 == 0")
     gate = _like_output(gate, out, "tile_conv2d: gate")
     residual = _like_output(residual, out, "tile_conv2d: residual")
-    views = _views(x, out, residual, gate)
-    call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
-         tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
-         _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
-         _ptr(residual), _ptr(gate), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
+    # 3x3 stride-1 layers: Winograd F(2x2, 3x3) on the matrix cores (csrc/wino.hip) unless
+    # PCONV_CONV3X3=direct asks for the fmaf-chain kernel (the bit-exact form the oracle restates)
+    wino = (k == 3 and stride == 1 and not sigmoid and gate is None and conv3x3_mode() == "wino" and
+            _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1 and
+            _aligned8(out) and (residual is None or _aligned8(residual)))
+    probe = conv_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(x.device))
+    if wino:
+        views = _views(x, out, residual)
+        call("pconv_conv3x3_wino", _ptr(x), _ptr(packed_wino_weight(owner, weight, stream)),
+             _ptr(bias.detach()) if bias is not None else None, _ptr(out), tn, cin, h, w, cout,
+             1 if slope is not None else 0, _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit),
+             int(npart), _ptr(residual), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
+    else:
+        packed = packed_conv_weight(owner, weight, stream)
+        views = _views(x, out, residual, gate)
+        call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
+             tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
+             _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
+             _ptr(residual), _ptr(gate), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
-        probe.records.append((conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w), "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo),
-                              flops, e0, e1))
+        kernel = "wino_conv3x3_kernel" if wino else conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w)
+        probe.records.append((kernel, "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo), flops, e0, e1))
     return out

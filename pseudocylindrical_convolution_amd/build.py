@@ -27,6 +27,7 @@ HIP_SOURCES = [
     "entropy.hip",
     "entropy_engine.hip",
     "conv.hip",
+    "wino.hip",
     "backward.hip",
     "engine.cpp",
     "coder.cpp",  # the engine drives the arithmetic coder natively

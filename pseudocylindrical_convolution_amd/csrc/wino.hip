@@ -1,0 +1,453 @@
+// 3x3 stride-1 tile convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// The 3x3 stride-1 layers are 80 % of the codec's convolution time (model_zoo_v2.py:41-45,83-86,
+// 158-164: ResidualBlock conv2, ResidualBlockV2 conv1/2, ResidualBlockDown/Up conv2, ResidualBlockUp
+// conv1).  The direct implicit GEMM (conv.hip) spends 9 multiply-adds per input channel, output channel
+// and pixel; the minimal-filtering form spends 16 per 2x2 output block = 4 per pixel:
+//
+//     V = Bt d B   (4x4 input block d, per input channel)        U = G g Gt   (per weight, packed once)
+//     M[xi] = sum_ci U[xi][co][ci] * V[xi][ci][tile]   xi = 0..15: sixteen independent [Cout x Cin] GEMMs
+//     Y = At M A   (2x2 outputs)
+//
+// i.e. 2.25 x fewer matrix-core operations for the same convolution -- what cuDNN picks for the
+// reference's fp32 3x3 layers too.  Results differ from the k-ascending fmaf chain of conv.hip by
+// rounding only (~1e-6 relative; the north-star bound is 1e-4); conv.hip stays the bit-exact form
+// (PCONV_CONV3X3=direct) and takes everything this kernel does not (stride 2, gates, odd sizes).
+//
+// Mapping.  A workgroup = 16 waves = 96 couts x 64 Winograd tiles (2 tile rows x 32 tile columns = 4 x 64
+// output pixels).  Wave xi owns GEMM xi: its 96 x 64 accumulator block is 3 x 2 MFMA tiles of 32 x 32
+// (96 registers), so the sixteen GEMMs use three quarters of the CU's register file as accumulators
+// -- the pixel tile cannot be larger, which is why a workgroup takes 96 and not 192 couts.
+//   * input patch (8 channels x 6 x 66) -> LDS by LDS-DMA, double buffered;
+//   * input transform by all 1024 threads: one (channel, tile) pair and one half of V each, LDS -> LDS,
+//     into a double-buffered V[xi][ci][tile] (the next chunk's transform runs before this chunk's MFMAs);
+//   * transformed weights U[xi]: nobody but wave xi reads them, so each wave streams its own slice
+//     through a PRIVATE two-stage LDS ring by LDS-DMA and waits with s_waitcnt only -- no barrier;
+//   * one workgroup barrier per 8 input channels (24 MFMAs per wave);
+//   * output transform: the sixteen M[xi] of an output meet in LDS (one 32-cout x 32-tile block of all
+//     xi per round, 64 KB), each thread turns one (cout, tile) into 2 x 2 outputs and applies the
+//     epilogue of the layer (bias, PReLU, residual, trim, or the Dtow pixel shuffle), stored as float2 /
+//     float4 runs.
+#include <atomic>
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+constexpr int kThreads = 1024, kWaves = 16;
+constexpr int TX = 32, TY = 2;                       // Winograd tiles of a workgroup
+constexpr int OROWS = 2 * TY, OCOLS = 2 * TX;        // 4 x 64 output pixels
+constexpr int CO = 96;                               // couts of a workgroup
+constexpr int KC = 8;                                // input channels per patch / V stage
+constexpr int KW = 4;                                // input channels per weight stage (wave private)
+constexpr int PR = OROWS + 2, PC = OCOLS + 2;        // 6 x 66 patch
+constexpr int PSZ = KC * PR * PC;                    // 3168
+constexpr int PLD = (PSZ + kThreads - 1) / kThreads; // 4 DMA dwords per thread
+constexpr int PBUF = 3200;
+constexpr int VSZ = 16 * KC * TX * TY;               // 8192
+constexpr int USZ = KW * CO;                         // 384
+constexpr int ULD = USZ / 64;                        // 6 DMA dwords per lane
+constexpr int kLdsFloats = 2 * PBUF + 2 * VSZ + kWaves * 2 * USZ;  // 35072 floats = 137 KB
+constexpr int ESZ = 16 * 32 * 32;                    // one exchange round of the output transform
+static_assert(ESZ <= kLdsFloats, "exchange buffer fits the stage memory");
+static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
+
+struct WView {
+  long long ts, cs;
+  int rs;
+};
+
+struct WEpilogue {
+  const float *bias, *slope, *residual;
+  const int32_t *col_limit;
+  int npart, act, trim, d2w;
+  WView vres;
+};
+
+// (cout, cin, 3, 3) -> U[cblock][xi][ci_pad][96] = (G g Gt)[xi], zero past cout / cin
+__global__ void wino_pack_kernel(const float *__restrict__ w, float *__restrict__ upk, int cout, int cin, int cin_pad,
+                                 int cblocks) {
+  const long long total = (long long)cblocks * cin_pad * CO;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % CO);
+  const int ci = (int)((i / CO) % cin_pad);
+  const int cb = (int)(i / ((long long)CO * cin_pad));
+  const int co = cb * CO + j;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) g[a][b] = (co < cout && ci < cin) ? w[(((size_t)co * cin + ci) * 3 + a) * 3 + b] : 0.f;
+  float r[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    r[0][b] = g[0][b];
+    r[1][b] = (g[0][b] + g[1][b] + g[2][b]) * 0.5f;
+    r[2][b] = (g[0][b] - g[1][b] + g[2][b]) * 0.5f;
+    r[3][b] = g[2][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const float u[4] = {r[a][0], (r[a][0] + r[a][1] + r[a][2]) * 0.5f, (r[a][0] - r[a][1] + r[a][2]) * 0.5f, r[a][2]};
+#pragma unroll
+    for (int b = 0; b < 4; b++) upk[(((size_t)cb * 16 + a * 4 + b) * cin_pad + ci) * CO + j] = u[b];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
+    const float *__restrict__ in, const float *__restrict__ upk, float *__restrict__ out, int cin, int cin_pad, int h,
+    int w, int cout, int ho, int wo, int tiles_r, int tiles_c, int cblocks, WView vin, WView vout, WEpilogue ep) {
+  extern __shared__ float lds[];
+  float *Ps = lds, *Vs = lds + 2 * PBUF, *Us = lds + 2 * PBUF + 2 * VSZ;
+
+  int b = blockIdx.x;
+  const int cb = b % cblocks;
+  b /= cblocks;
+  const int trx = b % tiles_r;
+  b /= tiles_r;
+  const int tcx = b % tiles_c;
+  const int t = b / tiles_c;
+  const int r0 = trx * OROWS, c0 = tcx * OCOLS, cout0 = cb * CO;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  float *outp = out + (size_t)t * vout.ts;
+  const int limit = ep.col_limit ? ep.col_limit[t % ep.npart] : wo;
+
+  if (c0 >= limit) {
+    // the tile lies entirely in the dead columns of this latitude band: zeros
+    for (int e = tid; e < CO * OROWS * OCOLS; e += kThreads) {
+      const int col = e % OCOLS, row = (e / OCOLS) % OROWS, co = cout0 + e / (OCOLS * OROWS);
+      if (co < cout && r0 + row < ho && c0 + col < wo) {
+        if (ep.d2w)
+          outp[(size_t)(co >> 2) * vout.cs + (size_t)(2 * (r0 + row) + ((co >> 1) & 1)) * vout.rs + 2 * (c0 + col) + (co & 1)] = 0.f;
+        else
+          outp[(size_t)co * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
+      }
+    }
+    return;
+  }
+
+  const float *inp = in + (size_t)t * vin.ts;
+  const int nchunk = cin_pad / KC, nsub = cin_pad / KW;
+
+  // ---- LDS-DMA: patch (all threads), weights (each wave its own slice) ----
+  unsigned xoffs[PLD];
+#pragma unroll
+  for (int j = 0; j < PLD; j++) {
+    int e = tid + j * kThreads;
+    e = e < PSZ ? e : 0;
+    const int pc = e % PC, pr = (e / PC) % PR, ci = e / (PC * PR);
+    int ir = r0 + pr, ic = c0 + pc;
+    ir = ir < h ? ir : h - 1;
+    ic = ic < w ? ic : w - 1;
+    xoffs[j] = (unsigned)((long long)ci * vin.cs + (long long)ir * vin.rs + ic);
+  }
+  const size_t xstep = (size_t)KC * vin.cs;
+  const int tail = cin % KC;  // channels of a ragged last chunk (their U rows are zero; read a real channel)
+  auto issue_patch = [&](int chunk, int buf) {
+    if (chunk >= nchunk) return;
+    const float *xb = inp + chunk * xstep;
+    const bool ragged = tail != 0 && chunk == nchunk - 1;
+#pragma unroll
+    for (int j = 0; j < PLD; j++) {
+      const int e = tid + j * kThreads;
+      if (e < PSZ) {
+        unsigned off = xoffs[j];
+        if (ragged) {
+          const int ci = e / (PC * PR);
+          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs);
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4,
+                                         0, 0);
+      }
+    }
+  };
+  const float *uw = upk + ((size_t)cb * 16 + wave) * cin_pad * CO + lane;
+  float *us_w = Us + wave * 2 * USZ;
+  auto issue_weights = [&](int sub) {
+    if (sub >= nsub) return;
+    const float *src = uw + (size_t)sub * USZ;
+    float *dst = us_w + (sub & 1) * USZ;
+#pragma unroll
+    for (int j = 0; j < ULD; j++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + j * 64), (lds_ptr_t *)(dst + j * 64), 4, 0, 0);
+  };
+
+  // ---- input transform: V = Bt d B, one (channel, tile) pair and one half of V per thread ----
+  const int tci = wave & 7, thalf = wave >> 3;      // channel inside the chunk, rows {0,1} or {2,3} of V
+  const int tty = lane >> 5, ttx = lane & 31;       // tile of this lane
+  auto transform = [&](int buf) {
+    const float *p = Ps + buf * PBUF + (tci * PR + 2 * tty + thalf) * PC + 2 * ttx;
+    f32x2 d[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      d[r][0] = *reinterpret_cast<const f32x2 *>(p + r * PC);
+      d[r][1] = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
+    }
+    float wa[4], wb[4];  // the two rows of Bt d this thread keeps
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float a = d[0][c >> 1][c & 1], bb = d[1][c >> 1][c & 1], cc = d[2][c >> 1][c & 1];
+      // thalf 0: rows (d0, d1, d2) -> Bt rows 0, 1 = d0 - d2, d1 + d2;  thalf 1: rows (d1, d2, d3) -> Bt rows 2, 3 = d2 - d1, d1 - d3
+      wa[c] = thalf ? bb - a : a - cc;
+      wb[c] = thalf ? a - cc : bb + cc;
+    }
+    float *v = Vs + buf * VSZ + ((thalf * 8) * KC + tci) * (TX * TY) + lane;  // xi = thalf*8 + {0..3} (row a), {4..7} (row b)
+    constexpr int XS = KC * TX * TY;  // stride between xi planes
+    v[0 * XS] = wa[0] - wa[2];
+    v[1 * XS] = wa[1] + wa[2];
+    v[2 * XS] = wa[2] - wa[1];
+    v[3 * XS] = wa[1] - wa[3];
+    v[4 * XS] = wb[0] - wb[2];
+    v[5 * XS] = wb[1] + wb[2];
+    v[6 * XS] = wb[2] - wb[1];
+    v[7 * XS] = wb[1] - wb[3];
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+  // ---- prologue ----
+  issue_patch(0, 0);
+  issue_weights(0);
+  issue_weights(1);
+  __builtin_amdgcn_s_waitcnt(0);  // (vmcnt(0) among others)
+  __syncthreads();
+  transform(0);
+  issue_patch(1, 1);
+
+  const float *a_w = us_w + half * CO + l31;                         // + stage*USZ + kp*2*CO + m*32
+  const float *b_w = Vs + ((size_t)wave * KC + half) * (TX * TY) + l31;  // + vbuf*VSZ + (s2*4 + kp*2)*64 + n*32
+
+  for (int chunk = 0; chunk < nchunk; chunk++) {
+    // patch(chunk+1) and this chunk's weights have landed (own pieces), then everybody's; V(chunk) is
+    // complete; the MFMAs of chunk-1 (last readers of V's other buffer) are done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int vb = chunk & 1;
+    if (chunk + 1 < nchunk) transform(vb ^ 1);
+    issue_patch(chunk + 2, vb);  // (read by transform(chunk), which finished before the barrier)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int sub = chunk * 2 + s2;
+      const float *aw = a_w + s2 * USZ;  // sub & 1 == s2
+      const float *bw = b_w + vb * VSZ + (s2 * 4) * (TX * TY);
+      float a[2][3], bv[2][2];
+#pragma unroll
+      for (int m = 0; m < 3; m++) a[0][m] = aw[m * 32];
+#pragma unroll
+      for (int n = 0; n < 2; n++) bv[0][n] = bw[n * 32];
+#pragma unroll
+      for (int kp = 0; kp < KW / 2; kp++) {
+        if (kp + 1 < KW / 2) {
+#pragma unroll
+          for (int m = 0; m < 3; m++) a[(kp + 1) & 1][m] = aw[(kp + 1) * 2 * CO + m * 32];
+#pragma unroll
+          for (int n = 0; n < 2; n++) bv[(kp + 1) & 1][n] = bw[(kp + 1) * 2 * (TX * TY) + n * 32];
+        }
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+          for (int n = 0; n < 2; n++)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][m], bv[kp & 1][n], acc[m][n], 0, 0, 0);
+      }
+      // this wave's reads of the weight stage are complete (their values fed the MFMAs): refill it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_weights(sub + 2);
+    }
+  }
+  __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
+
+  // ---- output transform + epilogue ----
+  float *Es = lds;  // [xi][32 couts][32 tiles]
+  const int act = ep.act;
+  const int trim_at = ep.trim ? limit : wo;
+  const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) Es[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[m][n][r];
+      __syncthreads();
+      if (!ep.d2w) {
+        const int row = wave * 2 + half, col = l31;  // cout inside the block, tile column
+        float mm[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; xi++) mm[xi] = Es[(xi * 32 + row) * 32 + col];
+        const int co = cout0 + m * 32 + row;
+        const int orow = r0 + 2 * n, ocol = c0 + 2 * col;
+        if (co < cout && ocol < wo) {
+          const float bco = ep.bias ? ep.bias[co] : 0.f;
+          const float sl = act == 1 ? ep.slope[co] : 0.f;
+          // Y = At M A, M[i][j] = mm[4 i + j]
+          float ta[2][4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            ta[0][j] = mm[j] + mm[4 + j] + mm[8 + j];
+            ta[1][j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
+          }
+#pragma unroll
+          for (int a2 = 0; a2 < 2; a2++) {
+            if (orow + a2 >= ho) continue;
+            float y0 = ta[a2][0] + ta[a2][1] + ta[a2][2] + bco;
+            float y1 = ta[a2][1] - ta[a2][2] - ta[a2][3] + bco;
+            if (act == 1) {
+              y0 = y0 < 0 ? y0 * sl : y0;
+              y1 = y1 < 0 ? y1 * sl : y1;
+            }
+            if (resp) {
+              const f32x2 rv = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)(orow + a2) * ep.vres.rs + ocol);
+              y0 = rv.x + y0;
+              y1 = rv.y + y1;
+            }
+            if (ocol >= trim_at) y0 = 0.f;
+            if (ocol + 1 >= trim_at) y1 = 0.f;
+            float *q = outp + (size_t)co * vout.cs + (size_t)(orow + a2) * vout.rs + ocol;
+            f32x2 yv = {y0, y1};
+            *reinterpret_cast<f32x2 *>(q) = yv;  // (wo is even: a 2x2 block never straddles the edge)
+          }
+        }
+      } else if (wave < 8) {
+        // Dtow by the store: couts co (even, sx = 0) and co + 1 (sx = 1) of a tile -> 4 consecutive
+        // outputs in each of 2 rows of channel co >> 2
+        const int rp = wave * 2 + half, col = l31;  // cout pair inside the block
+        float m0[16], m1[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; xi++) {
+          m0[xi] = Es[(xi * 32 + 2 * rp) * 32 + col];
+          m1[xi] = Es[(xi * 32 + 2 * rp + 1) * 32 + col];
+        }
+        const int co = cout0 + m * 32 + 2 * rp;
+        const int orow = r0 + 2 * n, ocol = c0 + 2 * col;
+        if (co < cout && ocol < wo) {
+          const float b0 = ep.bias ? ep.bias[co] : 0.f, b1 = ep.bias ? ep.bias[co + 1] : 0.f;
+          const float s0 = act == 1 ? ep.slope[co] : 0.f, s1 = act == 1 ? ep.slope[co + 1] : 0.f;
+          const int cq = co >> 2, sy = (co >> 1) & 1;
+#pragma unroll
+          for (int a2 = 0; a2 < 2; a2++) {
+            if (orow + a2 >= ho) continue;
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              t0[j] = a2 == 0 ? m0[j] + m0[4 + j] + m0[8 + j] : m0[4 + j] - m0[8 + j] - m0[12 + j];
+              t1[j] = a2 == 0 ? m1[j] + m1[4 + j] + m1[8 + j] : m1[4 + j] - m1[8 + j] - m1[12 + j];
+            }
+            float y00 = t0[0] + t0[1] + t0[2] + b0, y01 = t0[1] - t0[2] - t0[3] + b0;
+            float y10 = t1[0] + t1[1] + t1[2] + b1, y11 = t1[1] - t1[2] - t1[3] + b1;
+            if (act == 1) {
+              y00 = y00 < 0 ? y00 * s0 : y00;
+              y01 = y01 < 0 ? y01 * s0 : y01;
+              y10 = y10 < 0 ? y10 * s1 : y10;
+              y11 = y11 < 0 ? y11 * s1 : y11;
+            }
+            float *q = outp + (size_t)cq * vout.cs + (size_t)(2 * (orow + a2) + sy) * vout.rs + 2 * ocol;
+            *reinterpret_cast<float4 *>(q) = make_float4(y00, y10, y01, y11);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+inline WView dense_view(int c, int h, int w) { return {(long long)c * h * w, (long long)h * w, w}; }
+inline WView view_at(const long long *views, int i, int c, int h, int w) {
+  if (!views) return dense_view(c, h, w);
+  return {views[3 * i], views[3 * i + 1], (int)views[3 * i + 2]};
+}
+inline bool view_ok(const WView &v, int c, int h, int w) {
+  return v.rs >= w && v.cs >= (long long)(h - 1) * v.rs + w && v.ts >= (long long)(c - 1) * v.cs + (long long)(h - 1) * v.rs + w;
+}
+
+}  // namespace
+
+// floats of the packed Winograd weights of a (cout, cin, 3, 3) layer
+extern "C" long long pconv_wino_packed_size(int cout, int cin) {
+  const int cblocks = (cout + CO - 1) / CO, cin_pad = (cin + KC - 1) / KC * KC;
+  return (long long)cblocks * 16 * cin_pad * CO;
+}
+
+extern "C" int pconv_wino_pack_weight(const float *w, float *packed, int cout, int cin, void *stream) {
+  PCONV_REQUIRE(w && packed && cout > 0 && cin > 0, "wino_pack: bad argument");
+  const int cblocks = (cout + CO - 1) / CO, cin_pad = (cin + KC - 1) / KC * KC;
+  const long long total = (long long)cblocks * cin_pad * CO;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, packed,
+                     cout, cin, cin_pad, cblocks);
+  PCONV_LAUNCH_CHECK("wino_pack_weight");
+  return PCONV_OK;
+}
+
+// 1 when pconv_conv3x3_wino takes the layer (3x3 stride 1, even output size)
+extern "C" int pconv_wino_supported(int cin, int h, int w, int cout, int d2w) {
+  if (h < 4 || w < 4 || ((h - 2) & 1) || ((w - 2) & 1)) return 0;
+  if (cin < 8 || cout < 32) return 0;  // the 3-channel input layer and the 12-channel output layer stay direct
+  if (d2w && (cout & 3)) return 0;
+  return 1;
+}
+
+extern "C" int pconv_conv3x3_wino(const float *in, const float *packed_u, const float *bias, float *out, int tn, int cin,
+                                  int h, int w, int cout, int act, const float *slope, const int32_t *col_limit,
+                                  int npart, const float *residual, int trim, int d2w, const long long *views,
+                                  void *stream) {
+  PCONV_REQUIRE(in && packed_u && out, "conv3x3_wino: null pointer");
+  PCONV_REQUIRE(pconv_wino_supported(cin, h, w, cout, d2w), "conv3x3_wino: unsupported shape %d x %d x %d -> %d", cin, h, w,
+                cout);
+  PCONV_REQUIRE(act == 0 || (act == 1 && slope), "conv3x3_wino: bad activation %d", act);
+  PCONV_REQUIRE(!d2w || (!residual && !trim), "conv3x3_wino: depth-to-width takes no residual / trim");
+  PCONV_REQUIRE(!col_limit || npart > 0, "conv3x3_wino: col_limit needs npart");
+  PCONV_REQUIRE(!trim || col_limit, "conv3x3_wino: trim needs col_limit");
+  PCONV_REQUIRE(residual != out, "conv3x3_wino: residual must not alias the output");
+  const int ho = h - 2, wo = w - 2;
+  const int oc = d2w ? cout / 4 : cout, oh = d2w ? 2 * ho : ho, ow = d2w ? 2 * wo : wo;
+  const WView vin = view_at(views, 0, cin, h, w), vout = view_at(views, 1, oc, oh, ow);
+  const WEpilogue ep = {bias, slope, residual, col_limit, npart, act, trim, d2w, view_at(views, 2, cout, ho, wo)};
+  PCONV_REQUIRE(view_ok(vin, cin, h, w) && view_ok(vout, oc, oh, ow) && (!residual || view_ok(ep.vres, cout, ho, wo)),
+                "conv3x3_wino: strides overlap");
+  PCONV_REQUIRE((long long)(KC - 1) * vin.cs + (long long)(h - 1) * vin.rs + w < (1LL << 32),
+                "conv3x3_wino: input channel stride too large for 32-bit chunk offsets");
+  // float2 / float4 accesses: rows of every view start on even element offsets
+  PCONV_REQUIRE(vout.rs % 2 == 0 && vout.cs % 2 == 0 && vout.ts % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+                "conv3x3_wino: output rows must be 8-byte aligned");
+  PCONV_REQUIRE(!residual || (ep.vres.rs % 2 == 0 && ep.vres.cs % 2 == 0 && ep.vres.ts % 2 == 0 &&
+                              (reinterpret_cast<uintptr_t>(residual) & 7) == 0),
+                "conv3x3_wino: residual rows must be 8-byte aligned");
+  const int tiles_r = (ho + OROWS - 1) / OROWS, tiles_c = (wo + OCOLS - 1) / OCOLS;
+  const int cblocks = (cout + CO - 1) / CO, cin_pad = (cin + KC - 1) / KC * KC;
+  const long long grid = (long long)tn * tiles_r * tiles_c * cblocks;
+  PCONV_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_wino: grid %lld out of range", grid);
+  const size_t smem = (size_t)kLdsFloats * sizeof(float);
+  {
+    static std::atomic<unsigned long long> raised{0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+    const unsigned long long bit = 1ULL << (device & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv3x3_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) {
+        pconv_set_error("conv3x3_wino: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e));
+        return PCONV_ELAUNCH;
+      }
+      raised.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL(wino_conv3x3_kernel, dim3((unsigned)grid), dim3(kThreads), smem, as_stream(stream), in, packed_u, out,
+                     cin, cin_pad, h, w, cout, ho, wo, tiles_r, tiles_c, cblocks, vin, vout, ep);
+  PCONV_LAUNCH_CHECK("conv3x3_wino");
+  return PCONV_OK;
+}

@@ -21,6 +21,14 @@ def _detmath():
     yield
 
 
+@pytest.fixture(autouse=True)
+def _direct_conv(monkeypatch):
+    """this file pins the DIRECT tile convolution (one k-ascending fmaf chain per output, bit-exact
+    against the oracle's restatement); the Winograd form of the 3x3 stride-1 layers, the product's
+    default, has its own tests in tests/test_gpu_wino.py"""
+    monkeypatch.setenv("PCONV_CONV3X3", "direct")
+
+
 def P():
     from pseudocylindrical_convolution_amd import PCONV
     return PCONV
