@@ -48,14 +48,16 @@ constexpr int KW = 4;                                // input channels per weigh
 constexpr int PR = OROWS + 2, PC = OCOLS + 2;        // 6 x 66 patch
 constexpr int PSZ = KC * PR * PC;                    // 3168
 constexpr int PLD = (PSZ + kThreads - 1) / kThreads; // 4 DMA dwords per thread
-constexpr int PBUF = 3200;
+constexpr int PBUF = PLD * kThreads;                 // every wave issues all PLD pieces (the last one re-reads
+                                                     // element 0 past PSZ): uniform DMA counts for s_waitcnt vmcnt(n)
 constexpr int VSZ = 16 * KC * TX * TY;               // 8192
 constexpr int USZ = KW * CO;                         // 384
 constexpr int ULD = USZ / 64;                        // 6 DMA dwords per lane
 constexpr int kLdsFloats = 2 * PBUF + 2 * VSZ + kWaves * 2 * USZ;  // 35072 floats = 137 KB
 constexpr int ESZ = 16 * 32 * 32;                    // one exchange round of the output transform
-static_assert(ESZ <= kLdsFloats, "exchange buffer fits the stage memory");
+static_assert(2 * ESZ <= kLdsFloats, "the two exchange buffers fit the stage memory");
 static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
+static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
 
 struct WView {
   long long ts, cs;
@@ -160,15 +162,13 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #pragma unroll
     for (int j = 0; j < PLD; j++) {
       const int e = tid + j * kThreads;
-      if (e < PSZ) {
-        unsigned off = xoffs[j];
-        if (ragged) {
-          const int ci = e / (PC * PR);
-          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs);
-        }
-        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4,
-                                         0, 0);
+      unsigned off = xoffs[j];  // (elements past PSZ re-read element 0 into the buffer's slack)
+      if (ragged && e < PSZ) {
+        const int ci = e / (PC * PR);
+        if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs);
       }
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4, 0,
+                                       0);
     }
   };
   const float *uw = upk + ((size_t)cb * 16 + wave) * cin_pad * CO + lane;
@@ -234,9 +234,17 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   const float *b_w = Vs + ((size_t)wave * KC + half) * (TX * TY) + l31;  // + vbuf*VSZ + (s2*4 + kp*2)*64 + n*32
 
   for (int chunk = 0; chunk < nchunk; chunk++) {
-    // patch(chunk+1) and this chunk's weights have landed (own pieces), then everybody's; V(chunk) is
-    // complete; the MFMAs of chunk-1 (last readers of V's other buffer) are done
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // DMA issue order of a wave (oldest first) when it arrives here:
+    //   patch(chunk+1) [PLD], weights(2 chunk) [ULD], weights(2 chunk + 1) [ULD]
+    // the first two must have landed -- the last one, issued a moment ago at the end of the previous
+    // chunk, is not needed before this chunk's second half and stays in flight (counted wait).  Near the
+    // end of the reduction, where some of these are no longer issued, everything is waited for.
+    const bool steady = chunk + 2 < nchunk;  // uniform
+    if (steady && chunk > 0)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ULD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // then everybody's: V(chunk) is complete and the MFMAs of chunk-1 (last readers of V's other buffer) are done
     __syncthreads();
     const int vb = chunk & 1;
     if (chunk + 1 < nchunk) transform(vb ^ 1);
@@ -244,6 +252,13 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
       const int sub = chunk * 2 + s2;
+      if (s2 == 1) {
+        // in flight: weights(2 chunk + 1) [ULD], patch(chunk+2) [PLD], weights(2 chunk + 2) [ULD]
+        if (steady)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PLD + ULD) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       const float *aw = a_w + s2 * USZ;  // sub & 1 == s2
       const float *bw = b_w + vb * VSZ + (s2 * 4) * (TX * TY);
       float a[2][3], bv[2][2];
@@ -273,24 +288,35 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
 
   // ---- output transform + epilogue ----
-  float *Es = lds;  // [xi][32 couts][32 tiles]
+  // One 32-cout x 32-tile block of all sixteen M[xi] per round, through one of two exchange buffers
+  // (a round's readers are past their reads when they arrive at the next round's barrier: one barrier
+  // per round).  What the way out reads from memory (the residual) is requested before the exchange.
   const int act = ep.act;
   const int trim_at = ep.trim ? limit : wo;
   const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+  const int erow = wave * 2 + half, ecol = l31;  // this thread's cout inside the block (d2w: cout pair), tile column
+  const int ocol = c0 + 2 * ecol;
 #pragma unroll
   for (int m = 0; m < 3; m++) {
 #pragma unroll
     for (int n = 0; n < 2; n++) {
+      float *Es = lds + ((m * 2 + n) & 1) * ESZ;  // [xi][32 couts][32 tiles]
+      const int orow = r0 + 2 * n;
+      const int co = cout0 + m * 32 + (ep.d2w ? 2 * erow : erow);
+      f32x2 rv[2] = {{0.f, 0.f}, {0.f, 0.f}};
+      if (resp && co < cout && ocol < wo) {
+#pragma unroll
+        for (int a2 = 0; a2 < 2; a2++)
+          if (orow + a2 < ho)
+            rv[a2] = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)(orow + a2) * ep.vres.rs + ocol);
+      }
 #pragma unroll
       for (int r = 0; r < 16; r++) Es[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[m][n][r];
       __syncthreads();
       if (!ep.d2w) {
-        const int row = wave * 2 + half, col = l31;  // cout inside the block, tile column
         float mm[16];
 #pragma unroll
-        for (int xi = 0; xi < 16; xi++) mm[xi] = Es[(xi * 32 + row) * 32 + col];
-        const int co = cout0 + m * 32 + row;
-        const int orow = r0 + 2 * n, ocol = c0 + 2 * col;
+        for (int xi = 0; xi < 16; xi++) mm[xi] = Es[(xi * 32 + erow) * 32 + ecol];
         if (co < cout && ocol < wo) {
           const float bco = ep.bias ? ep.bias[co] : 0.f;
           const float sl = act == 1 ? ep.slope[co] : 0.f;
@@ -311,9 +337,8 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
               y1 = y1 < 0 ? y1 * sl : y1;
             }
             if (resp) {
-              const f32x2 rv = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)(orow + a2) * ep.vres.rs + ocol);
-              y0 = rv.x + y0;
-              y1 = rv.y + y1;
+              y0 = rv[a2].x + y0;
+              y1 = rv[a2].y + y1;
             }
             if (ocol >= trim_at) y0 = 0.f;
             if (ocol + 1 >= trim_at) y1 = 0.f;
@@ -325,15 +350,12 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       } else if (wave < 8) {
         // Dtow by the store: couts co (even, sx = 0) and co + 1 (sx = 1) of a tile -> 4 consecutive
         // outputs in each of 2 rows of channel co >> 2
-        const int rp = wave * 2 + half, col = l31;  // cout pair inside the block
         float m0[16], m1[16];
 #pragma unroll
         for (int xi = 0; xi < 16; xi++) {
-          m0[xi] = Es[(xi * 32 + 2 * rp) * 32 + col];
-          m1[xi] = Es[(xi * 32 + 2 * rp + 1) * 32 + col];
+          m0[xi] = Es[(xi * 32 + 2 * erow) * 32 + ecol];
+          m1[xi] = Es[(xi * 32 + 2 * erow + 1) * 32 + ecol];
         }
-        const int co = cout0 + m * 32 + 2 * rp;
-        const int orow = r0 + 2 * n, ocol = c0 + 2 * col;
         if (co < cout && ocol < wo) {
           const float b0 = ep.bias ? ep.bias[co] : 0.f, b1 = ep.bias ? ep.bias[co + 1] : 0.f;
           const float s0 = act == 1 ? ep.slope[co] : 0.f, s1 = act == 1 ? ep.slope[co + 1] : 0.f;
@@ -360,7 +382,6 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
           }
         }
       }
-      __syncthreads();
     }
   }
 }
