@@ -52,7 +52,7 @@ constexpr int PBUF = PLD * kThreads;                 // every wave issues all PL
                                                      // element 0 past PSZ): uniform DMA counts for s_waitcnt vmcnt(n)
 constexpr int VSZ = 16 * KC * TX * TY;               // 8192
 constexpr int USZ = KW * CO;                         // 384
-constexpr int ULD = USZ / 64;                        // 6 DMA dwords per lane
+constexpr int ULD = (USZ / 4 + 63) / 64;             // 2 16-byte DMA pieces per lane (the second one: lanes 0-31)
 constexpr int kLdsFloats = 2 * PBUF + 2 * VSZ + kWaves * 2 * USZ;  // 35072 floats = 137 KB
 constexpr int ESZ = 16 * 32 * 32;                    // one exchange round of the output transform
 static_assert(2 * ESZ <= kLdsFloats, "the two exchange buffers fit the stage memory");
@@ -157,6 +157,9 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   const int tail = cin % KC;  // channels of a ragged last chunk (their U rows are zero; read a real channel)
   auto issue_patch = [&](int chunk, int buf) {
     if (chunk >= nchunk) return;
+#ifdef PCONV_WINO_ABL_NOPDMA
+    if (chunk > 1) return;
+#endif
     const float *xb = inp + chunk * xstep;
     const bool ragged = tail != 0 && chunk == nchunk - 1;
 #pragma unroll
@@ -171,15 +174,22 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
                                        0);
     }
   };
-  const float *uw = upk + ((size_t)cb * 16 + wave) * cin_pad * CO + lane;
+  // a weight stage = KW x 96 floats = 96 lanes x 16 bytes: one full and one half 16-byte LDS-DMA
+  // instruction (dword pieces were 6 instructions; the vector-memory issue rate of the 16 waves, not
+  // the bytes, is what the weight stream costs: timing ablation in DESIGN.md)
+  const float *uw = upk + ((size_t)cb * 16 + wave) * cin_pad * CO + lane * 4;
   float *us_w = Us + wave * 2 * USZ;
   auto issue_weights = [&](int sub) {
     if (sub >= nsub) return;
+#ifdef PCONV_WINO_ABL_NOWDMA
+    if (sub > 1) return;
+#endif
     const float *src = uw + (size_t)sub * USZ;
     float *dst = us_w + (sub & 1) * USZ;
-#pragma unroll
-    for (int j = 0; j < ULD; j++)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + j * 64), (lds_ptr_t *)(dst + j * 64), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)dst, 16, 0, 0);
+    // (the half-empty second piece is issued by every lane's wave all the same: uniform DMA counts)
+    if (lane < USZ / 4 - 64)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + 256), (lds_ptr_t *)(dst + 256), 16, 0, 0);
   };
 
   // ---- input transform: V = Bt d B, one (channel, tile) pair and one half of V per thread ----
@@ -240,14 +250,21 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     // chunk, is not needed before this chunk's second half and stays in flight (counted wait).  Near the
     // end of the reduction, where some of these are no longer issued, everything is waited for.
     const bool steady = chunk + 2 < nchunk;  // uniform
+    // then everybody's: V(chunk) is complete (lgkmcnt(0): this thread's LDS writes) and the MFMAs of
+    // chunk-1, last readers of V's other buffer, are done.  Wait and barrier are one statement:
+    // __syncthreads() would wait for vmcnt(0), i.e. for the weights issued a moment ago.
+#ifdef PCONV_WINO_ABL_NOBAR
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
     if (steady && chunk > 0)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ULD) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ULD) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // then everybody's: V(chunk) is complete and the MFMAs of chunk-1 (last readers of V's other buffer) are done
-    __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     const int vb = chunk & 1;
+#ifndef PCONV_WINO_ABL_NOTRANSFORM
     if (chunk + 1 < nchunk) transform(vb ^ 1);
+#endif
     issue_patch(chunk + 2, vb);  // (read by transform(chunk), which finished before the barrier)
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
@@ -262,18 +279,27 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       const float *aw = a_w + s2 * USZ;  // sub & 1 == s2
       const float *bw = b_w + vb * VSZ + (s2 * 4) * (TX * TY);
       float a[2][3], bv[2][2];
+#ifdef PCONV_WINO_ABL_NOLDSREAD
+#pragma unroll
+      for (int m = 0; m < 3; m++) a[0][m] = a[1][m] = 1.f + m + sub;
+#pragma unroll
+      for (int n = 0; n < 2; n++) bv[0][n] = bv[1][n] = 2.f + n + sub;
+#else
 #pragma unroll
       for (int m = 0; m < 3; m++) a[0][m] = aw[m * 32];
 #pragma unroll
       for (int n = 0; n < 2; n++) bv[0][n] = bw[n * 32];
+#endif
 #pragma unroll
       for (int kp = 0; kp < KW / 2; kp++) {
+#ifndef PCONV_WINO_ABL_NOLDSREAD
         if (kp + 1 < KW / 2) {
 #pragma unroll
           for (int m = 0; m < 3; m++) a[(kp + 1) & 1][m] = aw[(kp + 1) * 2 * CO + m * 32];
 #pragma unroll
           for (int n = 0; n < 2; n++) bv[(kp + 1) & 1][n] = bw[(kp + 1) * 2 * (TX * TY) + n * 32];
         }
+#endif
 #pragma unroll
         for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -286,6 +312,17 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     }
   }
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
+#ifdef PCONV_WINO_ABL_NOEPILOGUE
+  if (cin != -12345) {  // timing ablation: keep the accumulators alive, skip the way out
+    float keep = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++) keep += acc[m][n][0];
+    if (keep == 123.456f) outp[0] = keep;
+    return;
+  }
+#endif
 
   // ---- output transform + epilogue ----
   // One 32-cout x 32-tile block of all sixteen M[xi] per round, through one of two exchange buffers
