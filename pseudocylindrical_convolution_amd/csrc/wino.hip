@@ -30,6 +30,7 @@
 //     float4 runs.
 #include <atomic>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -43,21 +44,25 @@ constexpr int kThreads = 1024, kWaves = 16;
 constexpr int TX = 32, TY = 2;                       // Winograd tiles of a workgroup
 constexpr int OROWS = 2 * TY, OCOLS = 2 * TX;        // 4 x 64 output pixels
 constexpr int CO = 96;                               // couts of a workgroup
-constexpr int KC = 8;                                // input channels per patch / V stage
-constexpr int KW = 4;                                // input channels per weight stage (wave private)
+constexpr int KC = 4;                                // input channels per stage (patch, V, weights)
 constexpr int PR = OROWS + 2, PC = OCOLS + 2;        // 6 x 66 patch
-constexpr int PSZ = KC * PR * PC;                    // 3168
-constexpr int PLD = (PSZ + kThreads - 1) / kThreads; // 4 DMA dwords per thread
+constexpr int PSZ = KC * PR * PC;                    // 1584
+constexpr int PLD = (PSZ + kThreads - 1) / kThreads; // 2 DMA dwords per thread
 constexpr int PBUF = PLD * kThreads;                 // every wave issues all PLD pieces (the last one re-reads
                                                      // element 0 past PSZ): uniform DMA counts for s_waitcnt vmcnt(n)
-constexpr int VSZ = 16 * KC * TX * TY;               // 8192
-constexpr int USZ = KW * CO;                         // 384
+constexpr int PRING = 2;                             // patch stages
+constexpr int VSZ = 16 * KC * TX * TY;               // 4096: V[xi][ci][tile], double buffered
+constexpr int USZ = KC * CO;                         // 384: a wave's weight stage [ci][96]
+constexpr int URING = 4;                             // weight stages per wave
 constexpr int ULD = (USZ / 4 + 63) / 64;             // 2 16-byte DMA pieces per lane (the second one: lanes 0-31)
-constexpr int kLdsFloats = 2 * PBUF + 2 * VSZ + kWaves * 2 * USZ;  // 35072 floats = 137 KB
+constexpr int kLdsFloats = PRING * PBUF + 2 * VSZ + kWaves * URING * USZ;  // 38912 floats = 152 KB
 constexpr int ESZ = 16 * 32 * 32;                    // one exchange round of the output transform
 static_assert(2 * ESZ <= kLdsFloats, "the two exchange buffers fit the stage memory");
+static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS of a CU");
 static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
 static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
+static_assert(URING == 4 && PRING == 2, "the main loop is unrolled over four chunks: ring slots are compile-time");
+static_assert(kWaves == 4 * KC, "transform: one (channel, row of V) per wave");
 
 struct WView {
   long long ts, cs;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     const float *__restrict__ in, const float *__restrict__ upk, float *__restrict__ out, int cin, int cin_pad, int h,
     int w, int cout, int ho, int wo, int tiles_r, int tiles_c, int cblocks, WView vin, WView vout, WEpilogue ep) {
   extern __shared__ float lds[];
-  float *Ps = lds, *Vs = lds + 2 * PBUF, *Us = lds + 2 * PBUF + 2 * VSZ;
+  float *Ps = lds, *Vs = lds + PRING * PBUF, *Us = lds + PRING * PBUF + 2 * VSZ;
 
   int b = blockIdx.x;
   const int cb = b % cblocks;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   }
 
   const float *inp = in + (size_t)t * vin.ts;
-  const int nchunk = cin_pad / KC, nsub = cin_pad / KW;
+  const int nchunk = cin_pad / KC;
 
   // ---- LDS-DMA: patch (all threads), weights (each wave its own slice) ----
   unsigned xoffs[PLD];
@@ -154,73 +159,59 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     xoffs[j] = (unsigned)((long long)ci * vin.cs + (long long)ir * vin.rs + ic);
   }
   const size_t xstep = (size_t)KC * vin.cs;
-  const int tail = cin % KC;  // channels of a ragged last chunk (their U rows are zero; read a real channel)
-  auto issue_patch = [&](int chunk, int buf) {
-    if (chunk >= nchunk) return;
+  auto issue_patch = [&](int chunk, int buf, bool guard) {
+    if (guard && chunk >= nchunk) return;
 #ifdef PCONV_WINO_ABL_NOPDMA
-    if (chunk > 1) return;
+    if (chunk >= PRING) return;
 #endif
     const float *xb = inp + chunk * xstep;
-    const bool ragged = tail != 0 && chunk == nchunk - 1;
 #pragma unroll
-    for (int j = 0; j < PLD; j++) {
-      const int e = tid + j * kThreads;
-      unsigned off = xoffs[j];  // (elements past PSZ re-read element 0 into the buffer's slack)
-      if (ragged && e < PSZ) {
-        const int ci = e / (PC * PR);
-        if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs);
-      }
-      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4, 0,
-                                       0);
-    }
+    for (int j = 0; j < PLD; j++)  // (elements past PSZ re-read element 0 into the buffer's slack)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + xoffs[j]), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64),
+                                       4, 0, 0);
   };
-  // a weight stage = KW x 96 floats = 96 lanes x 16 bytes: one full and one half 16-byte LDS-DMA
+  // a weight stage = KC x 96 floats = 96 lanes x 16 bytes: one full and one half 16-byte LDS-DMA
   // instruction (dword pieces were 6 instructions; the vector-memory issue rate of the 16 waves, not
   // the bytes, is what the weight stream costs: timing ablation in DESIGN.md)
   const float *uw = upk + ((size_t)cb * 16 + wave) * cin_pad * CO + lane * 4;
-  float *us_w = Us + wave * 2 * USZ;
-  auto issue_weights = [&](int sub) {
-    if (sub >= nsub) return;
+  float *us_w = Us + wave * URING * USZ;
+  auto issue_weights = [&](int chunk, bool guard) {
+    if (guard && chunk >= nchunk) return;
 #ifdef PCONV_WINO_ABL_NOWDMA
-    if (sub > 1) return;
+    if (chunk >= URING) return;
 #endif
-    const float *src = uw + (size_t)sub * USZ;
-    float *dst = us_w + (sub & 1) * USZ;
+    const float *src = uw + (size_t)chunk * USZ;
+    float *dst = us_w + (chunk % URING) * USZ;
     __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)dst, 16, 0, 0);
-    // (the half-empty second piece is issued by every lane's wave all the same: uniform DMA counts)
+    // (the half-empty second piece is issued by every wave all the same: uniform DMA counts)
     if (lane < USZ / 4 - 64)
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + 256), (lds_ptr_t *)(dst + 256), 16, 0, 0);
   };
 
-  // ---- input transform: V = Bt d B, one (channel, tile) pair and one half of V per thread ----
-  const int tci = wave & 7, thalf = wave >> 3;      // channel inside the chunk, rows {0,1} or {2,3} of V
-  const int tty = lane >> 5, ttx = lane & 31;       // tile of this lane
-  auto transform = [&](int buf) {
-    const float *p = Ps + buf * PBUF + (tci * PR + 2 * tty + thalf) * PC + 2 * ttx;
-    f32x2 d[3][2];
+  // ---- input transform: V = Bt d B.  A thread computes one row of V (4 of the 16 xi) of one (channel,
+  // tile) pair: wave -> (channel, row), lane -> tile.  Row i of Bt d: d0 - d2, d1 + d2, d2 - d1, d1 - d3.
+  const int tci = wave & 3, trow = wave >> 2;
+  const int tty = lane >> 5, ttx = lane & 31;
+  const int ra = trow == 0 ? 0 : 1, rb = trow == 3 ? 3 : 2;  // the two patch rows the Bt row combines
+  // signs as xor masks (a wave-uniform select per element would compile to scalar branch trees)
+  const unsigned sa = trow == 2 ? 0x80000000u : 0u, sb = (trow == 0 || trow == 3) ? 0x80000000u : 0u;
+  const int tp_off = (tci * PR + 2 * tty) * PC + 2 * ttx;
+  const int tv_off = ((trow * 4) * KC + tci) * (TX * TY) + lane;
+  auto transform = [&](int pbuf, int vbuf) {
+    const float *p = Ps + pbuf * PBUF + tp_off;
+    const f32x2 a0 = *reinterpret_cast<const f32x2 *>(p + ra * PC), a1 = *reinterpret_cast<const f32x2 *>(p + ra * PC + 2);
+    const f32x2 b0 = *reinterpret_cast<const f32x2 *>(p + rb * PC), b1 = *reinterpret_cast<const f32x2 *>(p + rb * PC + 2);
+    const float da[4] = {a0.x, a0.y, a1.x, a1.y}, db[4] = {b0.x, b0.y, b1.x, b1.y};
+    float wr[4];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-      d[r][0] = *reinterpret_cast<const f32x2 *>(p + r * PC);
-      d[r][1] = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
-    }
-    float wa[4], wb[4];  // the two rows of Bt d this thread keeps
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const float a = d[0][c >> 1][c & 1], bb = d[1][c >> 1][c & 1], cc = d[2][c >> 1][c & 1];
-      // thalf 0: rows (d0, d1, d2) -> Bt rows 0, 1 = d0 - d2, d1 + d2;  thalf 1: rows (d1, d2, d3) -> Bt rows 2, 3 = d2 - d1, d1 - d3
-      wa[c] = thalf ? bb - a : a - cc;
-      wb[c] = thalf ? a - cc : bb + cc;
-    }
-    float *v = Vs + buf * VSZ + ((thalf * 8) * KC + tci) * (TX * TY) + lane;  // xi = thalf*8 + {0..3} (row a), {4..7} (row b)
-    constexpr int XS = KC * TX * TY;  // stride between xi planes
-    v[0 * XS] = wa[0] - wa[2];
-    v[1 * XS] = wa[1] + wa[2];
-    v[2 * XS] = wa[2] - wa[1];
-    v[3 * XS] = wa[1] - wa[3];
-    v[4 * XS] = wb[0] - wb[2];
-    v[5 * XS] = wb[1] + wb[2];
-    v[6 * XS] = wb[2] - wb[1];
-    v[7 * XS] = wb[1] - wb[3];
+    for (int c = 0; c < 4; c++)
+      wr[c] = __uint_as_float(__float_as_uint(da[c]) ^ sa) + __uint_as_float(__float_as_uint(db[c]) ^ sb);
+    float *v = Vs + vbuf * VSZ + tv_off;  // xi = 4 trow + j
+    constexpr int XS = KC * TX * TY;      // stride between xi planes
+    v[0 * XS] = wr[0] - wr[2];
+    v[1 * XS] = wr[1] + wr[2];
+    v[2 * XS] = wr[2] - wr[1];
+    v[3 * XS] = wr[1] - wr[3];
   };
 
   f32x16 acc[3][2];
@@ -232,83 +223,89 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
   // ---- prologue ----
-  issue_patch(0, 0);
-  issue_weights(0);
-  issue_weights(1);
+  issue_patch(0, 0, true);
+#pragma unroll
+  for (int k = 0; k < URING; k++) issue_weights(k, true);
+  issue_patch(1, 1, true);
   __builtin_amdgcn_s_waitcnt(0);  // (vmcnt(0) among others)
   __syncthreads();
-  transform(0);
-  issue_patch(1, 1);
+  transform(0, 0);
 
-  const float *a_w = us_w + half * CO + l31;                         // + stage*USZ + kp*2*CO + m*32
-  const float *b_w = Vs + ((size_t)wave * KC + half) * (TX * TY) + l31;  // + vbuf*VSZ + (s2*4 + kp*2)*64 + n*32
+  const float *a_w = us_w + half * CO + l31;                             // + stage*USZ + kp*2*CO + m*32
+  const float *b_w = Vs + ((size_t)wave * KC + half) * (TX * TY) + l31;  // + vbuf*VSZ + kp*2*64 + n*32
 
-  for (int chunk = 0; chunk < nchunk; chunk++) {
-    // DMA issue order of a wave (oldest first) when it arrives here:
-    //   patch(chunk+1) [PLD], weights(2 chunk) [ULD], weights(2 chunk + 1) [ULD]
-    // the first two must have landed -- the last one, issued a moment ago at the end of the previous
-    // chunk, is not needed before this chunk's second half and stays in flight (counted wait).  Near the
-    // end of the reduction, where some of these are no longer issued, everything is waited for.
-    const bool steady = chunk + 2 < nchunk;  // uniform
-    // then everybody's: V(chunk) is complete (lgkmcnt(0): this thread's LDS writes) and the MFMAs of
-    // chunk-1, last readers of V's other buffer, are done.  Wait and barrier are one statement:
-    // __syncthreads() would wait for vmcnt(0), i.e. for the weights issued a moment ago.
+  // One chunk (KC input channels).  U = chunk % 4 is a compile-time ring slot (the loop below is unrolled
+  // over four chunks), so are the patch / V buffers (U & 1).  DMA issue order of a wave, one patch stage
+  // and one weight stage per chunk:  ... patch(chunk+1), weights(chunk+3) | patch(chunk+2), weights(chunk+4).
+  // On arrival patch(chunk+1) -- and with it everything older, weights(chunk) included -- must have landed;
+  // weights(chunk+3), issued a moment ago, stays in flight (counted wait).  Then everybody's: V(chunk) is
+  // complete (lgkmcnt(0): this thread's LDS writes) and the MFMAs of chunk-1, last readers of V's other
+  // buffer, are done.  Wait and barrier are one asm statement: __syncthreads() would wait for vmcnt(0).
+  // STEADY = every stream is still issuing (chunk + 4 < nchunk, chunk > 0): no guards, counted wait.
+  auto body = [&](auto u_c, auto steady_c, int chunk) {
+    constexpr int U = decltype(u_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    constexpr int vb = U & 1;
 #ifdef PCONV_WINO_ABL_NOBAR
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
-    if (steady && chunk > 0)
+    if (STEADY)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ULD) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-    const int vb = chunk & 1;
 #ifndef PCONV_WINO_ABL_NOTRANSFORM
-    if (chunk + 1 < nchunk) transform(vb ^ 1);
+    if (STEADY || chunk + 1 < nchunk) transform(vb ^ 1, vb ^ 1);
 #endif
-    issue_patch(chunk + 2, vb);  // (read by transform(chunk), which finished before the barrier)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      const int sub = chunk * 2 + s2;
-      if (s2 == 1) {
-        // in flight: weights(2 chunk + 1) [ULD], patch(chunk+2) [PLD], weights(2 chunk + 2) [ULD]
-        if (steady)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PLD + ULD) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      const float *aw = a_w + s2 * USZ;  // sub & 1 == s2
-      const float *bw = b_w + vb * VSZ + (s2 * 4) * (TX * TY);
-      float a[2][3], bv[2][2];
+    issue_patch(chunk + 2, vb, !STEADY);  // (that stage was read by transform(chunk), before the barrier)
+    const float *aw = a_w + U * USZ;
+    const float *bw = b_w + vb * VSZ;
+    float a[2][3], bv[2][2];
 #ifdef PCONV_WINO_ABL_NOLDSREAD
 #pragma unroll
-      for (int m = 0; m < 3; m++) a[0][m] = a[1][m] = 1.f + m + sub;
+    for (int m = 0; m < 3; m++) a[0][m] = a[1][m] = 1.f + m + chunk;
 #pragma unroll
-      for (int n = 0; n < 2; n++) bv[0][n] = bv[1][n] = 2.f + n + sub;
+    for (int n = 0; n < 2; n++) bv[0][n] = bv[1][n] = 2.f + n + chunk;
 #else
 #pragma unroll
-      for (int m = 0; m < 3; m++) a[0][m] = aw[m * 32];
+    for (int m = 0; m < 3; m++) a[0][m] = aw[m * 32];
 #pragma unroll
-      for (int n = 0; n < 2; n++) bv[0][n] = bw[n * 32];
+    for (int n = 0; n < 2; n++) bv[0][n] = bw[n * 32];
 #endif
 #pragma unroll
-      for (int kp = 0; kp < KW / 2; kp++) {
+    for (int kp = 0; kp < KC / 2; kp++) {
 #ifndef PCONV_WINO_ABL_NOLDSREAD
-        if (kp + 1 < KW / 2) {
+      if (kp + 1 < KC / 2) {
 #pragma unroll
-          for (int m = 0; m < 3; m++) a[(kp + 1) & 1][m] = aw[(kp + 1) * 2 * CO + m * 32];
+        for (int m = 0; m < 3; m++) a[(kp + 1) & 1][m] = aw[(kp + 1) * 2 * CO + m * 32];
 #pragma unroll
-          for (int n = 0; n < 2; n++) bv[(kp + 1) & 1][n] = bw[(kp + 1) * 2 * (TX * TY) + n * 32];
-        }
+        for (int n = 0; n < 2; n++) bv[(kp + 1) & 1][n] = bw[(kp + 1) * 2 * (TX * TY) + n * 32];
+      }
 #endif
 #pragma unroll
-        for (int m = 0; m < 3; m++)
+      for (int m = 0; m < 3; m++)
 #pragma unroll
-          for (int n = 0; n < 2; n++)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][m], bv[kp & 1][n], acc[m][n], 0, 0, 0);
-      }
-      // this wave's reads of the weight stage are complete (their values fed the MFMAs): refill it
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_weights(sub + 2);
+        for (int n = 0; n < 2; n++)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][m], bv[kp & 1][n], acc[m][n], 0, 0, 0);
+    }
+    // this wave's reads of the weight stage are complete (their values fed the MFMAs): refill it
+#ifndef PCONV_WINO_ABL_NOLGKM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    issue_weights(chunk + URING, !STEADY);
+  };
+  using std::integral_constant;
+  for (int c4 = 0; c4 < nchunk; c4 += 4) {  // nchunk is a multiple of 4 (cin % 16 == 0)
+    if (c4 > 0 && c4 + 8 <= nchunk) {
+      body(integral_constant<int, 0>{}, integral_constant<bool, true>{}, c4);
+      body(integral_constant<int, 1>{}, integral_constant<bool, true>{}, c4 + 1);
+      body(integral_constant<int, 2>{}, integral_constant<bool, true>{}, c4 + 2);
+      body(integral_constant<int, 3>{}, integral_constant<bool, true>{}, c4 + 3);
+    } else {
+      body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, c4);
+      body(integral_constant<int, 1>{}, integral_constant<bool, false>{}, c4 + 1);
+      body(integral_constant<int, 2>{}, integral_constant<bool, false>{}, c4 + 2);
+      body(integral_constant<int, 3>{}, integral_constant<bool, false>{}, c4 + 3);
     }
   }
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
@@ -453,7 +450,7 @@ extern "C" int pconv_wino_pack_weight(const float *w, float *packed, int cout, i
 // 1 when pconv_conv3x3_wino takes the layer (3x3 stride 1, even output size)
 extern "C" int pconv_wino_supported(int cin, int h, int w, int cout, int d2w) {
   if (h < 4 || w < 4 || ((h - 2) & 1) || ((w - 2) & 1)) return 0;
-  if (cin < 8 || cout < 32) return 0;  // the 3-channel input layer and the 12-channel output layer stay direct
+  if (cin < 16 || cin % 16 || cout < 32) return 0;  // the 3-channel input layer and the 12-channel output layer stay direct
   if (d2w && (cout & 3)) return 0;
   return 1;
 }

@@ -38,7 +38,7 @@ def data(tn, cin, h, w, cout, seed=5):
 
 @pytest.mark.parametrize("cfg", [
     # tn, cin, h, w, cout
-    (2, 192, 6, 70, 192), (1, 96, 6, 66, 96), (16, 192, 4, 130, 192), (1, 192, 10, 258, 768), (3, 24, 8, 40, 40),
+    (2, 192, 6, 70, 192), (1, 96, 6, 66, 96), (16, 192, 4, 130, 192), (1, 192, 10, 258, 768), (3, 32, 8, 40, 40), (2, 16, 6, 36, 32),
     (2, 192, 68, 260, 192), (1, 96, 12, 1028, 96),
 ])
 def test_wino_matches_direct_kernel_and_float64(cfg, hip_backend, monkeypatch):
