@@ -14,19 +14,23 @@
 // rounding only (~1e-6 relative; the north-star bound is 1e-4); conv.hip stays the bit-exact form
 // (PCONV_CONV3X3=direct) and takes everything this kernel does not (stride 2, gates, odd sizes).
 //
-// Mapping.  A workgroup = 16 waves = 96 couts x 64 Winograd tiles (2 tile rows x 32 tile columns = 4 x 64
-// output pixels).  Wave xi owns GEMM xi: its 96 x 64 accumulator block is 3 x 2 MFMA tiles of 32 x 32
-// (96 registers), so the sixteen GEMMs use three quarters of the CU's register file as accumulators
-// -- the pixel tile cannot be larger, which is why a workgroup takes 96 and not 192 couts.
-//   * input patch (8 channels x 6 x 66) -> LDS by LDS-DMA, double buffered;
-//   * input transform by all 1024 threads: one (channel, tile) pair and one half of V each, LDS -> LDS,
-//     into a double-buffered V[xi][ci][tile] (the next chunk's transform runs before this chunk's MFMAs);
-//   * transformed weights U[xi]: nobody but wave xi reads them, so each wave streams its own slice
-//     through a PRIVATE two-stage LDS ring by LDS-DMA and waits with s_waitcnt only -- no barrier;
-//   * one workgroup barrier per 8 input channels (24 MFMAs per wave);
+// Mapping.  A workgroup = 8 waves = 96 couts x 64 Winograd tiles (2 tile rows x 32 tile columns = 4 x 64
+// output pixels).  Wave w owns the GEMMs xi = 2w, 2w+1: two 96 x 64 accumulator blocks of 3 x 2 MFMA tiles
+// of 32 x 32 = 192 registers, so the sixteen GEMMs use three quarters of the CU's register file as
+// accumulators -- the pixel tile cannot be larger, which is why a workgroup takes 96 and not 192 couts --
+// and a wave still has ~60 registers for operands in flight (two waves per SIMD, 256 registers each;
+// the first version, sixteen waves of one GEMM and 128 registers, had none: 207 vs ... TFLOP/s).
+//   * input patch (4 channels x 6 x 66) -> LDS by LDS-DMA, double buffered;
+//   * input transform by all 512 threads: one (channel, tile) pair and one half of V each, LDS -> LDS,
+//     into a double-buffered V[xi][ci][tile]; its LDS reads are issued ahead of the chunk's matrix block,
+//     its arithmetic and writes after it;
+//   * transformed weights U[xi]: nobody but the wave that owns xi reads them, so each wave streams its own
+//     slice through a PRIVATE four-stage LDS ring by 16-byte LDS-DMA and waits with s_waitcnt only;
+//   * one workgroup barrier per 4 input channels (24 MFMAs per wave), main loop unrolled over four chunks
+//     (ring slots are compile-time constants);
 //   * output transform: the sixteen M[xi] of an output meet in LDS (one 32-cout x 32-tile block of all
-//     xi per round, 64 KB), each thread turns one (cout, tile) into 2 x 2 outputs and applies the
-//     epilogue of the layer (bias, PReLU, residual, trim, or the Dtow pixel shuffle), stored as float2 /
+//     xi per round, 64 KB, two buffers), each thread turns (cout, tile) pairs into 2 x 2 outputs and applies
+//     the epilogue of the layer (bias, PReLU, residual, trim, or the Dtow pixel shuffle), stored as float2 /
 //     float4 runs.
 #include <atomic>
 #include <stdlib.h>
@@ -40,29 +44,31 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void glb_ptr_t;
 
-constexpr int kThreads = 1024, kWaves = 16;
+constexpr int kThreads = 512, kWaves = 8;
+constexpr int XW = 2;                                // GEMMs (xi) per wave
 constexpr int TX = 32, TY = 2;                       // Winograd tiles of a workgroup
 constexpr int OROWS = 2 * TY, OCOLS = 2 * TX;        // 4 x 64 output pixels
 constexpr int CO = 96;                               // couts of a workgroup
 constexpr int KC = 4;                                // input channels per stage (patch, V, weights)
 constexpr int PR = OROWS + 2, PC = OCOLS + 2;        // 6 x 66 patch
 constexpr int PSZ = KC * PR * PC;                    // 1584
-constexpr int PLD = (PSZ + kThreads - 1) / kThreads; // 2 DMA dwords per thread
+constexpr int PLD = (PSZ + kThreads - 1) / kThreads; // 4 DMA dwords per thread
 constexpr int PBUF = PLD * kThreads;                 // every wave issues all PLD pieces (the last one re-reads
                                                      // element 0 past PSZ): uniform DMA counts for s_waitcnt vmcnt(n)
 constexpr int PRING = 2;                             // patch stages
 constexpr int VSZ = 16 * KC * TX * TY;               // 4096: V[xi][ci][tile], double buffered
-constexpr int USZ = KC * CO;                         // 384: a wave's weight stage [ci][96]
+constexpr int USZ = KC * XW * CO;                    // 768: a wave's weight stage [ci][xi & 1][96]
 constexpr int URING = 4;                             // weight stages per wave
-constexpr int ULD = (USZ / 4 + 63) / 64;             // 2 16-byte DMA pieces per lane (the second one: lanes 0-31)
-constexpr int kLdsFloats = PRING * PBUF + 2 * VSZ + kWaves * URING * USZ;  // 38912 floats = 152 KB
+constexpr int ULD = USZ / 4 / 64;                    // 3 16-byte DMA pieces per lane
+constexpr int kLdsFloats = PRING * PBUF + 2 * VSZ + kWaves * URING * USZ;  // 36864 floats = 144 KB
 constexpr int ESZ = 16 * 32 * 32;                    // one exchange round of the output transform
 static_assert(2 * ESZ <= kLdsFloats, "the two exchange buffers fit the stage memory");
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS of a CU");
 static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
+static_assert(USZ % 256 == 0, "weight stage = whole 16-byte DMA instructions");
 static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
 static_assert(URING == 4 && PRING == 2, "the main loop is unrolled over four chunks: ring slots are compile-time");
-static_assert(kWaves == 4 * KC, "transform: one (channel, row of V) per wave");
+static_assert(kWaves == 2 * KC && kWaves * XW == 16, "transform: one (channel, half of V) per wave; two GEMMs per wave");
 
 struct WView {
   long long ts, cs;
@@ -76,7 +82,8 @@ struct WEpilogue {
   WView vres;
 };
 
-// (cout, cin, 3, 3) -> U[cblock][xi][ci_pad][96] = (G g Gt)[xi], zero past cout / cin
+// (cout, cin, 3, 3) -> U[cblock][xi / 2][ci_pad][xi & 1][96] = (G g Gt)[xi], zero past cout / cin
+// (the two GEMMs of a wave interleaved per channel: a stage of KC channels is one contiguous 3 KB run)
 __global__ void wino_pack_kernel(const float *__restrict__ w, float *__restrict__ upk, int cout, int cin, int cin_pad,
                                  int cblocks) {
   const long long total = (long long)cblocks * cin_pad * CO;
@@ -103,8 +110,58 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, float *__restrict_
   for (int a = 0; a < 4; a++) {
     const float u[4] = {r[a][0], (r[a][0] + r[a][1] + r[a][2]) * 0.5f, (r[a][0] - r[a][1] + r[a][2]) * 0.5f, r[a][2]};
 #pragma unroll
-    for (int b = 0; b < 4; b++) upk[(((size_t)cb * 16 + a * 4 + b) * cin_pad + ci) * CO + j] = u[b];
+    for (int b = 0; b < 4; b++) {
+      const int xi = a * 4 + b;
+      upk[((((size_t)cb * kWaves + xi / XW) * cin_pad + ci) * XW + (xi % XW)) * CO + j] = u[b];
+    }
   }
+}
+
+// LDS operand reads of the matrix block, issued by hand: `ds_read_b32 dst, base offset:imm` with the whole
+// offset (ring slot, GEMM, k-pair, fragment: compile-time) in the 16-bit immediate, and COUNTED waits --
+// before the MFMAs of a step only that step's five reads must have landed, the five of the next step,
+// issued after them, stay in flight (LDS returns in order).  Left to itself the compiler waits for
+// lgkmcnt(0) right after every read: with two waves per SIMD the read latency would sit on the matrix pipe.
+template <int OFF>
+__device__ __forceinline__ float wino_lds_read(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <int PENDING>
+__device__ __forceinline__ void wino_wait(float (&a)[3], float (&b)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]) : "n"(PENDING));
+}
+
+// operands of step ST = (GEMM x, k-pair kp) of the chunk in weight slot U / V buffer VB
+template <int U, int VB, int ST>
+__device__ __forceinline__ void wino_read_step(float (&a)[3], float (&b)[2], unsigned abase, unsigned bbase) {
+  constexpr int x = ST >> 1, kp = ST & 1;
+  constexpr int aoff = (U * USZ + (kp * 2 * XW + x) * CO) * 4;
+  constexpr int boff = (VB * VSZ + (x * KC + kp * 2) * (TX * TY)) * 4;
+  a[0] = wino_lds_read<aoff>(abase);
+  a[1] = wino_lds_read<aoff + 128>(abase);
+  a[2] = wino_lds_read<aoff + 256>(abase);
+  b[0] = wino_lds_read<boff>(bbase);
+  b[1] = wino_lds_read<boff + 128>(bbase);
+}
+
+template <int U, int VB, int ST>
+__device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&a)[2][3], float (&b)[2][2], unsigned abase,
+                                               unsigned bbase) {
+  constexpr int NST = 2 * XW;
+  if constexpr (ST + 1 < NST) wino_read_step<U, VB, ST + 1>(a[(ST + 1) & 1], b[(ST + 1) & 1], abase, bbase);
+  wino_wait<(ST + 1 < NST) ? 5 : 0>(a[ST & 1], b[ST & 1]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+      acc[ST >> 1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ST & 1][m], b[ST & 1][n], acc[ST >> 1][m][n], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1>(acc, a, b, abase, bbase);
 }
 
 __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
@@ -166,14 +223,16 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #endif
     const float *xb = inp + chunk * xstep;
 #pragma unroll
-    for (int j = 0; j < PLD; j++)  // (elements past PSZ re-read element 0 into the buffer's slack)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + xoffs[j]), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64),
-                                       4, 0, 0);
+    for (int j = 0; j < PLD; j++) {  // (elements past PSZ re-read element 0 into the buffer's slack)
+      unsigned xo = xoffs[j];
+      asm volatile("" : "+v"(xo));
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + xo), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4, 0,
+                                       0);
+    }
   };
-  // a weight stage = KC x 96 floats = 96 lanes x 16 bytes: one full and one half 16-byte LDS-DMA
-  // instruction (dword pieces were 6 instructions; the vector-memory issue rate of the 16 waves, not
-  // the bytes, is what the weight stream costs: timing ablation in DESIGN.md)
-  const float *uw = upk + ((size_t)cb * 16 + wave) * cin_pad * CO + lane * 4;
+  // a weight stage = KC channels x the wave's two GEMMs x 96 floats = 3 KB contiguous in the packed
+  // weights: three 16-byte LDS-DMA instructions
+  const float *uw = upk + ((size_t)cb * kWaves + wave) * cin_pad * XW * CO;  // wave-uniform (scalar registers)
   float *us_w = Us + wave * URING * USZ;
   auto issue_weights = [&](int chunk, bool guard) {
     if (guard && chunk >= nchunk) return;
@@ -182,45 +241,67 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #endif
     const float *src = uw + (size_t)chunk * USZ;
     float *dst = us_w + (chunk % URING) * USZ;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)dst, 16, 0, 0);
-    // (the half-empty second piece is issued by every wave all the same: uniform DMA counts)
-    if (lane < USZ / 4 - 64)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + 256), (lds_ptr_t *)(dst + 256), 16, 0, 0);
+    // (opaque lane offset: hoisted out of the loop as a 64-bit per-lane pointer it costs two registers
+    // the matrix loop does not have -- a spill there reloads through vmcnt, i.e. waits for every DMA)
+    unsigned lo = (unsigned)lane * 4u;
+    asm volatile("" : "+v"(lo));
+#pragma unroll
+    for (int j = 0; j < ULD; j++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + j * 256 + lo), (lds_ptr_t *)(dst + j * 256), 16, 0, 0);
   };
 
-  // ---- input transform: V = Bt d B.  A thread computes one row of V (4 of the 16 xi) of one (channel,
-  // tile) pair: wave -> (channel, row), lane -> tile.  Row i of Bt d: d0 - d2, d1 + d2, d2 - d1, d1 - d3.
-  const int tci = wave & 3, trow = wave >> 2;
+  // ---- input transform: V = Bt d B, one (channel, tile) pair and one half of V (rows {0,1} or {2,3})
+  // per thread: wave -> (channel, half), lane -> tile.  Rows of Bt d: d0 - d2, d1 + d2, d2 - d1, d1 - d3.
+  // In two parts, so that the LDS reads are issued ahead of a matrix block and the arithmetic / writes
+  // come after it.
+  const int tci = wave & 3, thalf = wave >> 2;
+  const bool early = wave < 4;  // (uniform) see the chunk body
   const int tty = lane >> 5, ttx = lane & 31;
-  const int ra = trow == 0 ? 0 : 1, rb = trow == 3 ? 3 : 2;  // the two patch rows the Bt row combines
-  // signs as xor masks (a wave-uniform select per element would compile to scalar branch trees)
-  const unsigned sa = trow == 2 ? 0x80000000u : 0u, sb = (trow == 0 || trow == 3) ? 0x80000000u : 0u;
-  const int tp_off = (tci * PR + 2 * tty) * PC + 2 * ttx;
-  const int tv_off = ((trow * 4) * KC + tci) * (TX * TY) + lane;
-  auto transform = [&](int pbuf, int vbuf) {
+  const int tp_off = (tci * PR + 2 * tty + thalf) * PC + 2 * ttx;  // rows d[thalf .. thalf + 2]
+  const int tv_off = ((thalf * 8) * KC + tci) * (TX * TY) + lane;  // xi = 8 thalf + {0..3 | 4..7}
+  struct TransformRows {
+    f32x2 d[3][2];
+  };
+  auto transform_read = [&](int pbuf) {
     const float *p = Ps + pbuf * PBUF + tp_off;
-    const f32x2 a0 = *reinterpret_cast<const f32x2 *>(p + ra * PC), a1 = *reinterpret_cast<const f32x2 *>(p + ra * PC + 2);
-    const f32x2 b0 = *reinterpret_cast<const f32x2 *>(p + rb * PC), b1 = *reinterpret_cast<const f32x2 *>(p + rb * PC + 2);
-    const float da[4] = {a0.x, a0.y, a1.x, a1.y}, db[4] = {b0.x, b0.y, b1.x, b1.y};
-    float wr[4];
+    TransformRows tr;
 #pragma unroll
-    for (int c = 0; c < 4; c++)
-      wr[c] = __uint_as_float(__float_as_uint(da[c]) ^ sa) + __uint_as_float(__float_as_uint(db[c]) ^ sb);
-    float *v = Vs + vbuf * VSZ + tv_off;  // xi = 4 trow + j
-    constexpr int XS = KC * TX * TY;      // stride between xi planes
-    v[0 * XS] = wr[0] - wr[2];
-    v[1 * XS] = wr[1] + wr[2];
-    v[2 * XS] = wr[2] - wr[1];
-    v[3 * XS] = wr[1] - wr[3];
+    for (int r = 0; r < 3; r++) {
+      tr.d[r][0] = *reinterpret_cast<const f32x2 *>(p + r * PC);
+      tr.d[r][1] = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
+    }
+    return tr;
+  };
+  auto transform_write = [&](const TransformRows &tr, int vbuf) {
+    float wa[4], wb[4];  // the two rows of Bt d this thread keeps
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float a = tr.d[0][c >> 1][c & 1], bb = tr.d[1][c >> 1][c & 1], cc = tr.d[2][c >> 1][c & 1];
+      const float t1 = a - cc, t2 = bb - a, t3 = bb + cc;
+      wa[c] = thalf ? t2 : t1;  // thalf 0: d0 - d2, d1 + d2;  thalf 1 (rows d1, d2, d3): d2 - d1, d1 - d3
+      wb[c] = thalf ? t1 : t3;
+    }
+    float *v = Vs + vbuf * VSZ + tv_off;
+    constexpr int XS = KC * TX * TY;  // stride between xi planes
+    v[0 * XS] = wa[0] - wa[2];
+    v[1 * XS] = wa[1] + wa[2];
+    v[2 * XS] = wa[2] - wa[1];
+    v[3 * XS] = wa[1] - wa[3];
+    v[4 * XS] = wb[0] - wb[2];
+    v[5 * XS] = wb[1] + wb[2];
+    v[6 * XS] = wb[2] - wb[1];
+    v[7 * XS] = wb[1] - wb[3];
   };
 
-  f32x16 acc[3][2];
+  f32x16 acc[XW][3][2];
 #pragma unroll
-  for (int m = 0; m < 3; m++)
+  for (int x = 0; x < XW; x++)
 #pragma unroll
-    for (int n = 0; n < 2; n++)
+    for (int m = 0; m < 3; m++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[x][m][n][r] = 0.f;
 
   // ---- prologue ----
   issue_patch(0, 0, true);
@@ -229,10 +310,13 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   issue_patch(1, 1, true);
   __builtin_amdgcn_s_waitcnt(0);  // (vmcnt(0) among others)
   __syncthreads();
-  transform(0, 0);
+  transform_write(transform_read(0), 0);
 
-  const float *a_w = us_w + half * CO + l31;                             // + stage*USZ + kp*2*CO + m*32
-  const float *b_w = Vs + ((size_t)wave * KC + half) * (TX * TY) + l31;  // + vbuf*VSZ + kp*2*64 + n*32
+  // per-lane LDS byte addresses of the operand fragments (see wino_read_step): A = weights
+  // [stage][ci = 2 kp + half][x][96], B = V[vbuf][xi = 2 wave + x][ci = 2 kp + half][tile]
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);  // low half of the flat address = LDS offset
+  const unsigned abase = lds0 + (unsigned)((us_w - lds) + half * XW * CO + l31) * 4u;
+  const unsigned bbase = lds0 + (unsigned)((Vs - lds) + ((wave * XW) * KC + half) * (TX * TY) + l31) * 4u;
 
   // One chunk (KC input channels).  U = chunk % 4 is a compile-time ring slot (the loop below is unrolled
   // over four chunks), so are the patch / V buffers (U & 1).  DMA issue order of a wave, one patch stage
@@ -254,68 +338,53 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+    const bool more = STEADY || chunk + 1 < nchunk;
+    // The two waves of a SIMD (w and w + 4) run the same code between the same barriers: left alone, both
+    // would be in their transform (no MFMA issued) at the same time.  Waves 0-3 transform patch(chunk+1)
+    // BEFORE their matrix block, waves 4-7 AFTER it: one of the pair is always on the matrix pipe.
 #ifndef PCONV_WINO_ABL_NOTRANSFORM
-    if (STEADY || chunk + 1 < nchunk) transform(vb ^ 1, vb ^ 1);
+    if (more && early) transform_write(transform_read(vb ^ 1), vb ^ 1);
 #endif
     issue_patch(chunk + 2, vb, !STEADY);  // (that stage was read by transform(chunk), before the barrier)
-    const float *aw = a_w + U * USZ;
-    const float *bw = b_w + vb * VSZ;
+    // four steps (GEMM x, k-pair kp), operands of step s+1 read before the MFMAs of step s
     float a[2][3], bv[2][2];
-#ifdef PCONV_WINO_ABL_NOLDSREAD
-#pragma unroll
-    for (int m = 0; m < 3; m++) a[0][m] = a[1][m] = 1.f + m + chunk;
-#pragma unroll
-    for (int n = 0; n < 2; n++) bv[0][n] = bv[1][n] = 2.f + n + chunk;
-#else
-#pragma unroll
-    for (int m = 0; m < 3; m++) a[0][m] = aw[m * 32];
-#pragma unroll
-    for (int n = 0; n < 2; n++) bv[0][n] = bw[n * 32];
-#endif
-#pragma unroll
-    for (int kp = 0; kp < KC / 2; kp++) {
-#ifndef PCONV_WINO_ABL_NOLDSREAD
-      if (kp + 1 < KC / 2) {
-#pragma unroll
-        for (int m = 0; m < 3; m++) a[(kp + 1) & 1][m] = aw[(kp + 1) * 2 * CO + m * 32];
-#pragma unroll
-        for (int n = 0; n < 2; n++) bv[(kp + 1) & 1][n] = bw[(kp + 1) * 2 * (TX * TY) + n * 32];
-      }
-#endif
-#pragma unroll
-      for (int m = 0; m < 3; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][m], bv[kp & 1][n], acc[m][n], 0, 0, 0);
-    }
+    wino_read_step<U, vb, 0>(a[0], bv[0], abase, bbase);
+    wino_mma_steps<U, vb, 0>(acc, a, bv, abase, bbase);
     // this wave's reads of the weight stage are complete (their values fed the MFMAs): refill it
-#ifndef PCONV_WINO_ABL_NOLGKM
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     issue_weights(chunk + URING, !STEADY);
+#ifndef PCONV_WINO_ABL_NOTRANSFORM
+    if (more && !early) transform_write(transform_read(vb ^ 1), vb ^ 1);
+#endif
   };
   using std::integral_constant;
-  for (int c4 = 0; c4 < nchunk; c4 += 4) {  // nchunk is a multiple of 4 (cin % 16 == 0)
-    if (c4 > 0 && c4 + 8 <= nchunk) {
-      body(integral_constant<int, 0>{}, integral_constant<bool, true>{}, c4);
-      body(integral_constant<int, 1>{}, integral_constant<bool, true>{}, c4 + 1);
-      body(integral_constant<int, 2>{}, integral_constant<bool, true>{}, c4 + 2);
-      body(integral_constant<int, 3>{}, integral_constant<bool, true>{}, c4 + 3);
-    } else {
-      body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, c4);
-      body(integral_constant<int, 1>{}, integral_constant<bool, false>{}, c4 + 1);
-      body(integral_constant<int, 2>{}, integral_constant<bool, false>{}, c4 + 2);
-      body(integral_constant<int, 3>{}, integral_constant<bool, false>{}, c4 + 3);
-    }
-  }
+  auto group = [&](auto steady_c, int c4) {
+    body(integral_constant<int, 0>{}, steady_c, c4);
+    body(integral_constant<int, 1>{}, steady_c, c4 + 1);
+    body(integral_constant<int, 2>{}, steady_c, c4 + 2);
+    body(integral_constant<int, 3>{}, steady_c, c4 + 3);
+  };
+  // nchunk is a multiple of 4 (cin % 16 == 0).  Three plain loops -- head, steady state, tail -- rather
+  // than one loop choosing between two bodies: with both versions inside one loop the register allocator
+  // moved accumulator tiles through scratch memory at the joins (5 x slower: scratch reloads wait on vmcnt,
+  // i.e. on every DMA in flight).
+  int c4 = 0;
+  group(integral_constant<bool, false>{}, c4);
+  c4 += 4;
+#pragma unroll 1
+  for (; c4 + 8 <= nchunk; c4 += 4) group(integral_constant<bool, true>{}, c4);
+#pragma unroll 1
+  for (; c4 < nchunk; c4 += 4) group(integral_constant<bool, false>{}, c4);
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
 #ifdef PCONV_WINO_ABL_NOEPILOGUE
   if (cin != -12345) {  // timing ablation: keep the accumulators alive, skip the way out
     float keep = 0.f;
 #pragma unroll
-    for (int m = 0; m < 3; m++)
+    for (int x = 0; x < XW; x++)
 #pragma unroll
-      for (int n = 0; n < 2; n++) keep += acc[m][n][0];
+      for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) keep += acc[x][m][n][0];
     if (keep == 123.456f) outp[0] = keep;
     return;
   }
@@ -324,64 +393,91 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   // ---- output transform + epilogue ----
   // One 32-cout x 32-tile block of all sixteen M[xi] per round, through one of two exchange buffers
   // (a round's readers are past their reads when they arrive at the next round's barrier: one barrier
-  // per round).  What the way out reads from memory (the residual) is requested before the exchange.
+  // per round).  A thread finishes two (cout, tile) pairs per round (d2w: one pair of couts of a tile).
+  // What the way out reads from memory (the residual) is requested before the exchange.
   const int act = ep.act;
   const int trim_at = ep.trim ? limit : wo;
   const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
-  const int erow = wave * 2 + half, ecol = l31;  // this thread's cout inside the block (d2w: cout pair), tile column
+  const int erow = wave * 2 + half, ecol = l31;  // cout inside the block (second pair: + 16; d2w: cout pair), tile column
   const int ocol = c0 + 2 * ecol;
+  // residual values of round k = (m, n): requested two rounds ahead (a round is ~1 us, a load from HBM
+  // under load 2-3 us: requested at the head of their own round every one of the six waits was exposed)
+  struct ResPair {
+    f32x2 v[2][2];
+  };
+  auto load_res = [&](int round) {
+    const int m = round >> 1, n = round & 1;
+    const int orow = r0 + 2 * n;
+    ResPair rp = {{{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}}};
+    if (resp && ocol < wo && round < 6) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int co = cout0 + m * 32 + erow + 16 * j;
+        if (co < cout) {
+#pragma unroll
+          for (int a2 = 0; a2 < 2; a2++)
+            if (orow + a2 < ho)
+              rp.v[j][a2] = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)(orow + a2) * ep.vres.rs + ocol);
+        }
+      }
+    }
+    return rp;
+  };
+  ResPair rq[2] = {load_res(0), load_res(1)};
 #pragma unroll
   for (int m = 0; m < 3; m++) {
 #pragma unroll
     for (int n = 0; n < 2; n++) {
       float *Es = lds + ((m * 2 + n) & 1) * ESZ;  // [xi][32 couts][32 tiles]
       const int orow = r0 + 2 * n;
-      const int co = cout0 + m * 32 + (ep.d2w ? 2 * erow : erow);
-      f32x2 rv[2] = {{0.f, 0.f}, {0.f, 0.f}};
-      if (resp && co < cout && ocol < wo) {
+      const ResPair rcur = rq[(m * 2 + n) & 1];
+      rq[(m * 2 + n) & 1] = load_res(m * 2 + n + 2);
 #pragma unroll
-        for (int a2 = 0; a2 < 2; a2++)
-          if (orow + a2 < ho)
-            rv[a2] = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)(orow + a2) * ep.vres.rs + ocol);
-      }
+      for (int x = 0; x < XW; x++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) Es[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[m][n][r];
+        for (int r = 0; r < 16; r++)
+          Es[((wave * XW + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[x][m][n][r];
       __syncthreads();
       if (!ep.d2w) {
-        float mm[16];
 #pragma unroll
-        for (int xi = 0; xi < 16; xi++) mm[xi] = Es[(xi * 32 + erow) * 32 + ecol];
-        if (co < cout && ocol < wo) {
-          const float bco = ep.bias ? ep.bias[co] : 0.f;
-          const float sl = act == 1 ? ep.slope[co] : 0.f;
-          // Y = At M A, M[i][j] = mm[4 i + j]
-          float ta[2][4];
+        for (int j = 0; j < 2; j++) {
+          const int row = erow + 16 * j;
+          float mm[16];
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            ta[0][j] = mm[j] + mm[4 + j] + mm[8 + j];
-            ta[1][j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
-          }
+          for (int xi = 0; xi < 16; xi++) mm[xi] = Es[(xi * 32 + row) * 32 + ecol];
+          const int co = cout0 + m * 32 + row;
+          if (co < cout && ocol < wo) {
+            const float bco = ep.bias ? ep.bias[co] : 0.f;
+            const float sl = act == 1 ? ep.slope[co] : 0.f;
+            // Y = At M A, M[i][j] = mm[4 i + j]
+            float ta[2][4];
 #pragma unroll
-          for (int a2 = 0; a2 < 2; a2++) {
-            if (orow + a2 >= ho) continue;
-            float y0 = ta[a2][0] + ta[a2][1] + ta[a2][2] + bco;
-            float y1 = ta[a2][1] - ta[a2][2] - ta[a2][3] + bco;
-            if (act == 1) {
-              y0 = y0 < 0 ? y0 * sl : y0;
-              y1 = y1 < 0 ? y1 * sl : y1;
+            for (int q = 0; q < 4; q++) {
+              ta[0][q] = mm[q] + mm[4 + q] + mm[8 + q];
+              ta[1][q] = mm[4 + q] - mm[8 + q] - mm[12 + q];
             }
-            if (resp) {
-              y0 = rv[a2].x + y0;
-              y1 = rv[a2].y + y1;
+#pragma unroll
+            for (int a2 = 0; a2 < 2; a2++) {
+              if (orow + a2 >= ho) continue;
+              float y0 = ta[a2][0] + ta[a2][1] + ta[a2][2] + bco;
+              float y1 = ta[a2][1] - ta[a2][2] - ta[a2][3] + bco;
+              if (act == 1) {
+                y0 = y0 < 0 ? y0 * sl : y0;
+                y1 = y1 < 0 ? y1 * sl : y1;
+              }
+              if (resp) {
+                y0 = rcur.v[j][a2].x + y0;
+                y1 = rcur.v[j][a2].y + y1;
+              }
+              if (ocol >= trim_at) y0 = 0.f;
+              if (ocol + 1 >= trim_at) y1 = 0.f;
+              float *q = outp + (size_t)co * vout.cs + (size_t)(orow + a2) * vout.rs + ocol;
+              f32x2 yv = {y0, y1};
+              *reinterpret_cast<f32x2 *>(q) = yv;  // (wo is even: a 2x2 block never straddles the edge)
             }
-            if (ocol >= trim_at) y0 = 0.f;
-            if (ocol + 1 >= trim_at) y1 = 0.f;
-            float *q = outp + (size_t)co * vout.cs + (size_t)(orow + a2) * vout.rs + ocol;
-            f32x2 yv = {y0, y1};
-            *reinterpret_cast<f32x2 *>(q) = yv;  // (wo is even: a 2x2 block never straddles the edge)
           }
         }
-      } else if (wave < 8) {
+      } else {
         // Dtow by the store: couts co (even, sx = 0) and co + 1 (sx = 1) of a tile -> 4 consecutive
         // outputs in each of 2 rows of channel co >> 2
         float m0[16], m1[16];
@@ -390,6 +486,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
           m0[xi] = Es[(xi * 32 + 2 * erow) * 32 + ecol];
           m1[xi] = Es[(xi * 32 + 2 * erow + 1) * 32 + ecol];
         }
+        const int co = cout0 + m * 32 + 2 * erow;
         if (co < cout && ocol < wo) {
           const float b0 = ep.bias ? ep.bias[co] : 0.f, b1 = ep.bias ? ep.bias[co + 1] : 0.f;
           const float s0 = act == 1 ? ep.slope[co] : 0.f, s1 = act == 1 ? ep.slope[co + 1] : 0.f;
@@ -399,9 +496,9 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
             if (orow + a2 >= ho) continue;
             float t0[4], t1[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              t0[j] = a2 == 0 ? m0[j] + m0[4 + j] + m0[8 + j] : m0[4 + j] - m0[8 + j] - m0[12 + j];
-              t1[j] = a2 == 0 ? m1[j] + m1[4 + j] + m1[8 + j] : m1[4 + j] - m1[8 + j] - m1[12 + j];
+            for (int q = 0; q < 4; q++) {
+              t0[q] = a2 == 0 ? m0[q] + m0[4 + q] + m0[8 + q] : m0[4 + q] - m0[8 + q] - m0[12 + q];
+              t1[q] = a2 == 0 ? m1[q] + m1[4 + q] + m1[8 + q] : m1[4 + q] - m1[8 + q] - m1[12 + q];
             }
             float y00 = t0[0] + t0[1] + t0[2] + b0, y01 = t0[1] - t0[2] - t0[3] + b0;
             float y10 = t1[0] + t1[1] + t1[2] + b1, y11 = t1[1] - t1[2] - t1[3] + b1;
