@@ -75,23 +75,56 @@ __global__ __launch_bounds__(kBlock) void pseudo_pad_kernel(
 // the interior columns a wider pad of the same buffer could have written before;
 // per halo row the whole row, as pseudo_pad_kernel defines it.  Interior columns
 // past the wrap are the producer's (it trims them to zero).
+// One workgroup per (tile-batch, channel) plane -- blockIdx.x = tc, blockIdx.y splits wide rows: the tile and
+// image indices are computed once per workgroup, a halo row is walked by consecutive lanes (coalesced), and no
+// element needs an integer division.  (r3: the first version decoded a flat 64-bit element index per ring element
+// in a grid-stride loop: four 64-bit divisions per element, 0.6 TB/s, the largest non-convolution, non-entropy
+// item of the codec: 15 ms of a 940 ms step.)
 __global__ __launch_bounds__(kBlock) void pseudo_pad_ring_kernel(
     float *__restrict__ buf, const int32_t *__restrict__ widths, const int32_t *__restrict__ src_tile,
     const int32_t *__restrict__ src_row, const int32_t *__restrict__ col, const float *__restrict__ wgt,
-    int c, int h, int w, int pad, int store, int npart, long long n_side, long long n_halo) {
+    int c, int h, int w, int pad, int store, int npart) {
   const int sh = h + 2 * store, sw = w + 2 * store;  // storage extent
   const int ow = w + 2 * pad, shift = store - pad;   // view extent / view -> storage offset
   const int per_row = 3 * pad + shift;
-  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_side + n_halo;
-       i += (long long)gridDim.x * kBlock) {
-    if (i < n_side) {
-      const int k = (int)(i % per_row);
-      const long long row = i / per_row;  // (tile-batch*c + channel)*h + r
-      const int r = (int)(row % h);
-      const long long tc = row / h;
-      const int tg = (int)((tc / c) % npart);
-      const int valid = widths[tg];
-      float *line = buf + ((size_t)tc * sh + store + r) * sw;  // storage row of data row r
+  const unsigned tc = blockIdx.x;                    // tile-batch * c + channel
+  const int pc = (int)(tc % (unsigned)c);
+  const unsigned tb = tc / (unsigned)c;
+  const int tg = (int)(tb % (unsigned)npart);
+  const unsigned img = tb / (unsigned)npart;
+  const int valid = widths[tg];
+  float *plane = buf + (size_t)tc * sh * sw;
+  // halo rows: 2 * pad rows of ow elements, columns strided over the workgroups of this plane
+  for (int q = 0; q < 2 * pad; q++) {
+    const int side = q >= pad, rr = side ? q - pad : q;
+    const int rview = side ? pad + h + rr : rr;
+    const int e = (tg * 2 + side) * pad + rr;
+    const int st = src_tile[e];
+    const int svalid = widths[st];
+    const float *src = buf + ((((size_t)(img * npart + st) * c + pc) * sh) + store + src_row[e]) * sw + store;
+    const int32_t *ecol = col + (size_t)e * w;
+    const float *ewgt = wgt + (size_t)e * w;
+    float *dst = plane + (size_t)(rview + shift) * sw + shift;
+    for (int j = blockIdx.y * kBlock + threadIdx.x; j < ow; j += gridDim.y * kBlock) {
+      float v = 0.f;
+      if (j < valid + 2 * pad) {
+        int x = j - pad;
+        x += (x < 0) ? valid : 0;
+        x -= (j >= valid + pad) ? valid : 0;
+        const int qc = ecol[x];
+        const float t = ewgt[x];
+        int q1 = qc + 1;
+        q1 = (q1 >= svalid) ? q1 - svalid : q1;
+        v = src[qc] * t + src[q1] * (1 - t);
+      }
+      dst[j] = v;
+    }
+  }
+  // side columns of the interior rows: per row 3 * pad + shift elements (see above), a thread per (row, k)
+  if (blockIdx.y == 0) {
+    for (int i = threadIdx.x; i < h * per_row; i += kBlock) {
+      const int r = i / per_row, k = i - r * per_row;
+      float *line = plane + (size_t)(store + r) * sw;  // storage row of data row r
       const float *data = line + store;
       int j;  // view column
       float v = 0.f;
@@ -109,35 +142,6 @@ __global__ __launch_bounds__(kBlock) void pseudo_pad_ring_kernel(
         if (j >= pad + w) continue;  // outside the interior: handled as ring
       }
       line[j + shift] = v;
-    } else {
-      const long long e0 = i - n_side;
-      const int j = (int)(e0 % ow);
-      const long long hr = e0 / ow;  // (tile-batch*c + channel)*2*pad + halo row index
-      const int q = (int)(hr % (2 * pad));
-      const long long tc = hr / (2 * pad);
-      const int pc = (int)(tc % c);
-      const long long tb = tc / c;
-      const int tg = (int)(tb % npart);
-      const long long img = tb / npart;
-      const int side = q >= pad, rr = side ? q - pad : q;
-      const int valid = widths[tg];
-      const int rview = side ? pad + h + rr : rr;
-      float v = 0.f;
-      if (j < valid + 2 * pad) {
-        int x = j - pad;
-        x += (x < 0) ? valid : 0;
-        x -= (j >= valid + pad) ? valid : 0;
-        const int e = (tg * 2 + side) * pad + rr;
-        const int st = src_tile[e];
-        const int svalid = widths[st];
-        const float *src = buf + ((((size_t)(img * npart + st) * c + pc) * sh) + store + src_row[e]) * sw + store;
-        const int qc = col[(size_t)e * w + x];
-        const float t = wgt[(size_t)e * w + x];
-        int q1 = qc + 1;
-        q1 = (q1 >= svalid) ? q1 - svalid : q1;
-        v = src[qc] * t + src[q1] * (1 - t);
-      }
-      buf[((size_t)tc * sh + rview + shift) * sw + j + shift] = v;
     }
   }
 }
@@ -267,10 +271,11 @@ extern "C" int pconv_pseudo_pad_ring(float *buf, const int32_t *widths, const in
   PCONV_REQUIRE(buf && widths && src_tile && src_row && col && wgt, "pseudo_pad_ring: null pointer");
   PCONV_REQUIRE(tn > 0 && tn % npart == 0 && c > 0 && h > 0 && w > 0 && pad > 0 && pad <= store,
                 "pseudo_pad_ring: bad shape tn=%d c=%d h=%d w=%d pad=%d store=%d", tn, c, h, w, pad, store);
-  const long long n_side = (long long)tn * c * h * (3 * pad + store - pad);
-  const long long n_halo = (long long)tn * c * 2 * pad * (w + 2 * pad);
-  hipLaunchKernelGGL(pseudo_pad_ring_kernel, dim3(pconv_grid(n_side + n_halo)), dim3(kBlock), 0, as_stream(stream),
-                     buf, widths, src_tile, src_row, col, wgt, c, h, w, pad, store, npart, n_side, n_halo);
+  const long long planes = (long long)tn * c;
+  PCONV_REQUIRE(planes <= 0x7fffffffLL, "pseudo_pad_ring: too many planes");
+  const int ysplit = (w + 2 * pad + 1023) / 1024;  // a workgroup walks up to four 256-column strips of a halo row
+  hipLaunchKernelGGL(pseudo_pad_ring_kernel, dim3((unsigned)planes, (unsigned)ysplit), dim3(kBlock), 0, as_stream(stream),
+                     buf, widths, src_tile, src_row, col, wgt, c, h, w, pad, store, npart);
   PCONV_LAUNCH_CHECK("pseudo_pad_ring");
   return PCONV_OK;
 }
