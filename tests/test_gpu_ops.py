@@ -462,3 +462,32 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
     # and against the oracle's fmaf chain on a slice of the batch
     ref = O.conv2d_chain(x[:1].cpu(), wt.cpu(), None, 1, None)
     assert torch.equal(resident[2][:1].cpu(), ref)   # tile 0 is live over its whole width
+
+
+def test_timeit_prints_like_the_reference_timer(capsys):
+    """`timeit=True` (last constructor argument of every op, base_opt.hpp:7-8, timer.h:32-44): events
+    around the op's call, `<head> Elapsed time : <ms> ms` on stdout"""
+    x = rnd(16, 8, 4, 64).to(DEV)
+    op = P().DtowOp(2, True, 0, True)
+    out = op.forward(x)[0]
+    assert tuple(out.shape) == (16, 2, 8, 128)
+    printed = capsys.readouterr().out
+    assert "DtowOp.forward Elapsed time : " in printed and printed.strip().endswith("ms")
+    quiet = P().DtowOp(2, True, 0, False)
+    quiet.forward(x)
+    assert capsys.readouterr().out == ""
+
+
+def test_hbm_probe_records_the_gather_kernels(monkeypatch):
+    """bench.py's `hbm` rows: every launch of the HBM-bound gather / permute ops is bracketed by events
+    with the algorithmic bytes of SURVEY 8d"""
+    rec = type("Probe", (), {"records": []})()
+    monkeypatch.setattr(P(), "hbm_probe", rec)
+    x = rnd(1, 3, 256, 512).to(DEV)
+    s = P().SphereSliceOp(16, 0, 0, W16, 0, False).forward(x)[0]
+    P().SphereUsliceOp(16, 0, 0, W16, 0, False).forward(s)
+    P().DtowOp(2, True, 0, False).forward(rnd(16, 8, 4, 64).to(DEV))
+    torch.cuda.synchronize()
+    kernels = [r[0] for r in rec.records]
+    assert kernels == ["slice_kernel", "uslice_kernel", "dtow2_kernel"]
+    assert rec.records[0][2] == 8.0 * x.numel() and all(r[3].elapsed_time(r[4]) > 0 for r in rec.records)
