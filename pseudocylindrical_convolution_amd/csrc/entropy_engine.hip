@@ -549,20 +549,51 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
                                 threadIdx.x);
     const float *wl = wl2[tc & 1];
     float acc[PP][GO];
+    if constexpr (PP == 4) {
+      // the four positions' chains as packed fp32 FMAs, two positions per instruction (v_pk_fma_f32: two
+      // IEEE fmas, the same bits as two v_fma_f32) -- r3: the loop was 12 scalar FMAs per LDS read, VALU-bound
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 p[2][GO];
 #pragma unroll
-    for (int j = 0; j < PP; j++)
+      for (int q = 0; q < 2; q++)
 #pragma unroll
-      for (int o = 0; o < GO; o++) acc[j][o] = 0.f;
+        for (int o = 0; o < GO; o++) p[q][o] = (f2){0.f, 0.f};
 #pragma unroll
-    for (int it = 0; it < ITER; it++) {
-      const int kk = lane + it * kWave;
-      const int kc = kk < RED ? kk : RED - 1;
-      const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);  // causally masked taps are zeros
+      for (int it = 0; it < ITER; it++) {
+        const int kk = lane + it * kWave;
+        const int kc = kk < RED ? kk : RED - 1;
+        const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);  // causally masked taps are zeros
 #pragma unroll
-      for (int j = 0; j < PP; j++) {
-        acc[j][0] = fmaf(xv[j][it], wv.x, acc[j][0]);
-        acc[j][1] = fmaf(xv[j][it], wv.y, acc[j][1]);
-        acc[j][2] = fmaf(xv[j][it], wv.z, acc[j][2]);
+        for (int q = 0; q < 2; q++) {
+          const f2 xx = {xv[2 * q][it], xv[2 * q + 1][it]};
+          p[q][0] = __builtin_elementwise_fma(xx, (f2){wv.x, wv.x}, p[q][0]);
+          p[q][1] = __builtin_elementwise_fma(xx, (f2){wv.y, wv.y}, p[q][1]);
+          p[q][2] = __builtin_elementwise_fma(xx, (f2){wv.z, wv.z}, p[q][2]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int o = 0; o < GO; o++) {
+          acc[2 * q][o] = p[q][o].x;
+          acc[2 * q + 1][o] = p[q][o].y;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PP; j++)
+#pragma unroll
+        for (int o = 0; o < GO; o++) acc[j][o] = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const int kk = lane + it * kWave;
+        const int kc = kk < RED ? kk : RED - 1;
+        const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);  // causally masked taps are zeros
+#pragma unroll
+        for (int j = 0; j < PP; j++) {
+          acc[j][0] = fmaf(xv[j][it], wv.x, acc[j][0]);
+          acc[j][1] = fmaf(xv[j][it], wv.y, acc[j][1]);
+          acc[j][2] = fmaf(xv[j][it], wv.z, acc[j][2]);
+        }
       }
     }
     if constexpr (PP == 4) {
