@@ -19,11 +19,11 @@
 // of 32 x 32 = 192 registers, so the sixteen GEMMs use three quarters of the CU's register file as
 // accumulators -- the pixel tile cannot be larger, which is why a workgroup takes 96 and not 192 couts --
 // and a wave still has ~60 registers for operands in flight (two waves per SIMD, 256 registers each;
-// the first version, sixteen waves of one GEMM and 128 registers, had none: 207 vs ... TFLOP/s).
+// the first version, sixteen waves of one GEMM and 128 registers, had none: 207 vs 214-224 TFLOP/s).
 //   * input patch (4 channels x 6 x 66) -> LDS by LDS-DMA, double buffered;
 //   * input transform by all 512 threads: one (channel, tile) pair and one half of V each, LDS -> LDS,
-//     into a double-buffered V[xi][ci][tile]; its LDS reads are issued ahead of the chunk's matrix block,
-//     its arithmetic and writes after it;
+//     into a double-buffered V[xi][ci][tile]; waves 0-3 do it before their matrix block, waves 4-7 after
+//     it (the two waves of a SIMD are never both off the matrix pipe);
 //   * transformed weights U[xi]: nobody but the wave that owns xi reads them, so each wave streams its own
 //     slice through a PRIVATE four-stage LDS ring by 16-byte LDS-DMA and waits with s_waitcnt only;
 //   * one workgroup barrier per 4 input channels (24 MFMAs per wave), main loop unrolled over four chunks
