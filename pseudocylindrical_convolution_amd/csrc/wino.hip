@@ -21,9 +21,9 @@
 // and a wave still has ~60 registers for operands in flight (two waves per SIMD, 256 registers each;
 // the first version, sixteen waves of one GEMM and 128 registers, had none: 207 vs 214-224 TFLOP/s).
 //   * input patch (4 channels x 6 x 66) -> LDS by LDS-DMA, double buffered;
-//   * input transform by all 512 threads: one (channel, tile) pair and one half of V each, LDS -> LDS,
-//     into a double-buffered V[xi][ci][tile]; waves 0-3 do it before their matrix block, waves 4-7 after
-//     it (the two waves of a SIMD are never both off the matrix pipe);
+//   * input transform LDS -> LDS into a double-buffered V[xi][ci][tile] by waves 0-3 (one per SIMD; all
+//     sixteen values of a (channel, tile) pair per thread) before their matrix block, while their SIMD
+//     partners, waves 4-7, are on the matrix pipe;
 //   * transformed weights U[xi]: nobody but the wave that owns xi reads them, so each wave streams its own
 //     slice through a PRIVATE four-stage LDS ring by 16-byte LDS-DMA and waits with s_waitcnt only;
 //   * one workgroup barrier per 4 input channels (24 MFMAs per wave), main loop unrolled over four chunks
@@ -31,7 +31,8 @@
 //   * output transform: the sixteen M[xi] of an output meet in LDS (one 32-cout x 32-tile block of all
 //     xi per round, 64 KB, two buffers), each thread turns (cout, tile) pairs into 2 x 2 outputs and applies
 //     the epilogue of the layer (bias, PReLU, residual, trim, or the Dtow pixel shuffle), stored as float2 /
-//     float4 runs.
+//     float4 runs.  (Measured alternative: three rounds with 16-byte writes / 8-byte reads -- half the LDS
+//     instructions -- is not faster: 5.04 vs 5.02 ms.)
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
@@ -68,7 +69,7 @@ static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
 static_assert(USZ % 256 == 0, "weight stage = whole 16-byte DMA instructions");
 static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
 static_assert(URING == 4 && PRING == 2, "the main loop is unrolled over four chunks: ring slots are compile-time");
-static_assert(kWaves == 2 * KC && kWaves * XW == 16, "transform: one (channel, half of V) per wave; two GEMMs per wave");
+static_assert(KC == 4 && kWaves * XW == 16, "transform: waves 0-3 take one channel of the stage each; two GEMMs per wave");
 
 struct WView {
   long long ts, cs;
@@ -250,47 +251,35 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + j * 256 + lo), (lds_ptr_t *)(dst + j * 256), 16, 0, 0);
   };
 
-  // ---- input transform: V = Bt d B, one (channel, tile) pair and one half of V (rows {0,1} or {2,3})
-  // per thread: wave -> (channel, half), lane -> tile.  Rows of Bt d: d0 - d2, d1 + d2, d2 - d1, d1 - d3.
-  // In two parts, so that the LDS reads are issued ahead of a matrix block and the arithmetic / writes
-  // come after it.
-  const int tci = wave & 3, thalf = wave >> 2;
-  const bool early = wave < 4;  // (uniform) see the chunk body
+  // ---- input transform: V = Bt d B.  Waves 0-3 (one per SIMD) do it: wave -> channel of the stage, lane ->
+  // tile, all sixteen V values of the (channel, tile) pair per thread: 8 LDS reads, 32 adds, 16 LDS writes.
+  // (Spread over all eight waves -- one half of V per thread -- the shared rows were read and combined twice:
+  // 2 x (6 reads + 28 adds + 8 writes); 214 -> 227 TFLOP/s.)  Rows of Bt d: d0 - d2, d1 + d2, d2 - d1, d1 - d3.
+  // The transform waves run it BEFORE their matrix block: their SIMD partner (wave + 4) is on the matrix pipe.
+  const bool early = wave < 4;  // (uniform)
   const int tty = lane >> 5, ttx = lane & 31;
-  const int tp_off = (tci * PR + 2 * tty + thalf) * PC + 2 * ttx;  // rows d[thalf .. thalf + 2]
-  const int tv_off = ((thalf * 8) * KC + tci) * (TX * TY) + lane;  // xi = 8 thalf + {0..3 | 4..7}
-  struct TransformRows {
-    f32x2 d[3][2];
-  };
-  auto transform_read = [&](int pbuf) {
-    const float *p = Ps + pbuf * PBUF + tp_off;
-    TransformRows tr;
+  auto transform_full = [&](int pbuf, int vbuf) {
+    const float *p = Ps + pbuf * PBUF + (wave * PR + 2 * tty) * PC + 2 * ttx;
+    float d[4][4];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-      tr.d[r][0] = *reinterpret_cast<const f32x2 *>(p + r * PC);
-      tr.d[r][1] = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
+    for (int r = 0; r < 4; r++) {
+      const f32x2 lo = *reinterpret_cast<const f32x2 *>(p + r * PC), hi = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
+      d[r][0] = lo.x, d[r][1] = lo.y, d[r][2] = hi.x, d[r][3] = hi.y;
     }
-    return tr;
-  };
-  auto transform_write = [&](const TransformRows &tr, int vbuf) {
-    float wa[4], wb[4];  // the two rows of Bt d this thread keeps
+    float *v = Vs + vbuf * VSZ + wave * (TX * TY) + lane;
+    constexpr int XS = KC * TX * TY;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      const float a = tr.d[0][c >> 1][c & 1], bb = tr.d[1][c >> 1][c & 1], cc = tr.d[2][c >> 1][c & 1];
-      const float t1 = a - cc, t2 = bb - a, t3 = bb + cc;
-      wa[c] = thalf ? t2 : t1;  // thalf 0: d0 - d2, d1 + d2;  thalf 1 (rows d1, d2, d3): d2 - d1, d1 - d3
-      wb[c] = thalf ? t1 : t3;
+      const float t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
+      d[0][c] = t0, d[1][c] = t1, d[2][c] = t2, d[3][c] = t3;
     }
-    float *v = Vs + vbuf * VSZ + tv_off;
-    constexpr int XS = KC * TX * TY;  // stride between xi planes
-    v[0 * XS] = wa[0] - wa[2];
-    v[1 * XS] = wa[1] + wa[2];
-    v[2 * XS] = wa[2] - wa[1];
-    v[3 * XS] = wa[1] - wa[3];
-    v[4 * XS] = wb[0] - wb[2];
-    v[5 * XS] = wb[1] + wb[2];
-    v[6 * XS] = wb[2] - wb[1];
-    v[7 * XS] = wb[1] - wb[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      v[(i * 4 + 0) * XS] = d[i][0] - d[i][2];
+      v[(i * 4 + 1) * XS] = d[i][1] + d[i][2];
+      v[(i * 4 + 2) * XS] = d[i][2] - d[i][1];
+      v[(i * 4 + 3) * XS] = d[i][1] - d[i][3];
+    }
   };
 
   f32x16 acc[XW][3][2];
@@ -310,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   issue_patch(1, 1, true);
   __builtin_amdgcn_s_waitcnt(0);  // (vmcnt(0) among others)
   __syncthreads();
-  transform_write(transform_read(0), 0);
+  if (early) transform_full(0, 0);
 
   // per-lane LDS byte addresses of the operand fragments (see wino_read_step): A = weights
   // [stage][ci = 2 kp + half][x][96], B = V[vbuf][xi = 2 wave + x][ci = 2 kp + half][tile]
@@ -339,11 +328,9 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     const bool more = STEADY || chunk + 1 < nchunk;
-    // The two waves of a SIMD (w and w + 4) run the same code between the same barriers: left alone, both
-    // would be in their transform (no MFMA issued) at the same time.  Waves 0-3 transform patch(chunk+1)
-    // BEFORE their matrix block, waves 4-7 AFTER it: one of the pair is always on the matrix pipe.
 #ifndef PCONV_WINO_ABL_NOTRANSFORM
-    if (more && early) transform_write(transform_read(vb ^ 1), vb ^ 1);
+    // waves 0-3: V(chunk+1) from patch(chunk+1), before their matrix block (see transform_full)
+    if (more && early) transform_full(vb ^ 1, vb ^ 1);
 #endif
     issue_patch(chunk + 2, vb, !STEADY);  // (that stage was read by transform(chunk), before the barrier)
     // four steps (GEMM x, k-pair kp), operands of step s+1 read before the MFMAs of step s
@@ -354,7 +341,6 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     issue_weights(chunk + URING, !STEADY);
 #ifndef PCONV_WINO_ABL_NOTRANSFORM
-    if (more && !early) transform_write(transform_read(vb ^ 1), vb ^ 1);
 #endif
   };
   using std::integral_constant;
