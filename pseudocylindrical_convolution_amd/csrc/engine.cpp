@@ -369,10 +369,11 @@ struct pconv_entropy_engine {
       stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
     }
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
-    // decoder chains run side by side, one per group.  Two groups by default: in the
-    // entropy probe four are 3-5 % faster at 4-8 frames, in the whole codec (bench.py)
-    // 4 % slower; eight make the chains wait for each other (4 hardware queues)
-    int ngroups = nimg >= 2 ? 2 : 1;
+    // decoder chains run side by side, one per group: two groups up to five frames, four from six on
+    // (r3, whole codec at 8 frames, host-driven chains: 2 / 3 / 4 groups 194-199 / 183-187 / 178-180 ms per
+    // decode; at 4 frames two groups of two on the queued chain stay best: profiles/round3_decode_groups.txt);
+    // eight make the chains wait for each other (4 hardware queues)
+    int ngroups = nimg >= 6 ? 4 : (nimg >= 2 ? 2 : 1);
     if (const char *env = getenv("PCONV_ENGINE_GROUPS")) ngroups = atoi(env);
     if (ngroups > nimg) ngroups = nimg;
     if (ngroups < 1) ngroups = 1;
@@ -779,12 +780,13 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
   //   Which one: the queued chain moves the CDF rows and the symbols by zero-copy accesses of the kernels
   //     themselves, the host-driven one by bulk copies; measured (MI355X, 4096x2048, two groups) queued /
   //     host-driven: 94 / 103 ms for one frame, 110 / 113 for two, 141 / 137 for four, 212 / 197 for eight
-  //     (four frames per group: 276 KB of rows per step).  PCONV_ENGINE_CHAIN=queued|host overrides.
+  //     (four frames per group: 276 KB of rows per step); r3: from six frames on four groups, host-driven
+  //     (8 frames: 178-180 ms; four groups on the queued chain 206-209).  PCONV_ENGINE_CHAIN=queued|host overrides.
   const char *chain_env = getenv("PCONV_ENGINE_CHAIN");
   const int ng = (int)e->groups.size();
   int largest = 0;
   for (const Group &g : e->groups) largest = std::max(largest, g.nimg);
-  const bool chained = chain_env ? chain_env[0] != 'h' : largest < 4;
+  const bool chained = chain_env ? chain_env[0] != 'h' : (largest < 4 && e->nimg < 6);
   std::vector<int> rcs(ng, PCONV_OK);
   std::vector<std::string> errors(ng);
   std::vector<double> waits(ng, 0.0), coders(ng, 0.0);
