@@ -69,6 +69,7 @@ static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
 static_assert(USZ % 256 == 0, "weight stage = whole 16-byte DMA instructions");
 static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
 static_assert(URING == 4 && PRING == 2, "the main loop is unrolled over four chunks: ring slots are compile-time");
+static_assert(XW == 2, "the way out stores a wave's two GEMMs by hand");
 static_assert(KC == 4 && kWaves * XW == 16, "transform: waves 0-3 take one channel of the stage each; two GEMMs per wave");
 
 struct WView {
@@ -165,8 +166,49 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
   if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1>(acc, a, b, abase, bbase);
 }
 
+// Eight accumulator registers -> LDS by `ds_write_addtid_b32` (address = M0 + offset + 4 * lane: no address
+// register, 2 issue cycles instead of ds_write_b32's 4).  M0 also carries the LDS base of the LDS-DMA
+// instructions, which the compiler tracks: it is saved and restored inside the statement.
+template <int OFF>
+__device__ __forceinline__ void wino_store8_addtid(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                                   float a7, unsigned base) {
+  static_assert(OFF >= 0 && OFF + 7 * 256 < 65536, "ds offset field is 16 bits");
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %9\n\t"
+      "s_nop 0\n\t"  // (M0 write -> add-tid LDS instruction: one wait state, not inserted for inline assembly)
+      "ds_write_addtid_b32 %1 offset:%10\n\t"
+      "ds_write_addtid_b32 %2 offset:%10+256\n\t"
+      "ds_write_addtid_b32 %3 offset:%10+512\n\t"
+      "ds_write_addtid_b32 %4 offset:%10+768\n\t"
+      "ds_write_addtid_b32 %5 offset:%10+1024\n\t"
+      "ds_write_addtid_b32 %6 offset:%10+1280\n\t"
+      "ds_write_addtid_b32 %7 offset:%10+1536\n\t"
+      "ds_write_addtid_b32 %8 offset:%10+1792\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(base), "n"(OFF)
+      : "memory");
+}
+
+// A wave's two 32 x 32 accumulator tiles -> exchange buffer BUF (byte BUF * 64 KB of the kernel's LDS, which starts at
+// offset 0 or close to it), Es[xi = 2 wave + x][r][lane].  The address of ds_write_addtid is
+// M0[15:0] + a 16-bit immediate: for the second buffer the 64 KB are split between the two.
+template <int BUF>
+__device__ __forceinline__ void wino_store_round(const f32x16 &c0, const f32x16 &c1, int wave, unsigned lds0) {
+  constexpr int M0_PART = BUF * 8188, IMM_PART = BUF * (ESZ * 4 - 8188);
+  static_assert(7 * 8192 + M0_PART < 65536 && IMM_PART + 31 * 256 < 65536, "address split of the second exchange buffer");
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds0) + (unsigned)(wave * (XW * 16 * 256) + M0_PART);
+  wino_store8_addtid<IMM_PART>(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], base);
+  wino_store8_addtid<IMM_PART + 8 * 256>(c0[8], c0[9], c0[10], c0[11], c0[12], c0[13], c0[14], c0[15], base);
+  wino_store8_addtid<IMM_PART + 16 * 256>(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7], base);
+  wino_store8_addtid<IMM_PART + 24 * 256>(c1[8], c1[9], c1[10], c1[11], c1[12], c1[13], c1[14], c1[15], base);
+}
+
+template <bool RES, bool D2W>
 __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
-    const float *__restrict__ in, const float *__restrict__ upk, float *__restrict__ out, int cin, int cin_pad, int h,
+    const float *__restrict__ in, const float *__restrict__ upk, float *out, int cin, int cin_pad, int h,
     int w, int cout, int ho, int wo, int tiles_r, int tiles_c, int cblocks, WView vin, WView vout, WEpilogue ep) {
   extern __shared__ float lds[];
   float *Ps = lds, *Vs = lds + PRING * PBUF, *Us = lds + PRING * PBUF + 2 * VSZ;
@@ -192,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     for (int e = tid; e < CO * OROWS * OCOLS; e += kThreads) {
       const int col = e % OCOLS, row = (e / OCOLS) % OROWS, co = cout0 + e / (OCOLS * OROWS);
       if (co < cout && r0 + row < ho && c0 + col < wo) {
-        if (ep.d2w)
+        if (D2W)
           outp[(size_t)(co >> 2) * vout.cs + (size_t)(2 * (r0 + row) + ((co >> 1) & 1)) * vout.rs + 2 * (c0 + col) + (co & 1)] = 0.f;
         else
           outp[(size_t)co * vout.cs + (size_t)(r0 + row) * vout.rs + c0 + col] = 0.f;
@@ -361,6 +403,19 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   for (; c4 + 8 <= nchunk; c4 += 4) group(integral_constant<bool, true>{}, c4);
 #pragma unroll 1
   for (; c4 < nchunk; c4 += 4) group(integral_constant<bool, false>{}, c4);
+  // bias / PReLU slope of the thread's six couts (three 32-cout blocks x two), requested here: inside a
+  // round these loads sat behind the stores of the round before (vmcnt counts loads and stores)
+  const int erow = wave * 2 + half, ecol = l31;  // cout inside the block (second pair: + 16; d2w: cout pair), tile column
+  float ebias[3][2], eslope[3][2];
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int co = cout0 + m * 32 + (D2W ? 2 * erow + j : erow + 16 * j);
+      co = co < cout ? co : cout - 1;
+      ebias[m][j] = ep.bias ? ep.bias[co] : 0.f;
+      eslope[m][j] = ep.act == 1 ? ep.slope[co] : 0.f;
+    }
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
 #ifdef PCONV_WINO_ABL_NOEPILOGUE
   if (cin != -12345) {  // timing ablation: keep the accumulators alive, skip the way out
@@ -383,27 +438,31 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   // What the way out reads from memory (the residual) is requested before the exchange.
   const int act = ep.act;
   const int trim_at = ep.trim ? limit : wo;
-  const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
-  const int erow = wave * 2 + half, ecol = l31;  // cout inside the block (second pair: + 16; d2w: cout pair), tile column
+  const float *resp = RES ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
   const int ocol = c0 + 2 * ecol;
   // residual values of round k = (m, n): requested two rounds ahead (a round is ~1 us, a load from HBM
   // under load 2-3 us: requested at the head of their own round every one of the six waits was exposed)
   struct ResPair {
     f32x2 v[2][2];
   };
+  // (addresses clamped into the view instead of guarded, and the kind of layer -- residual / plain / Dtow
+  // -- a template parameter of the kernel instead of a uniform branch: with a branch around a load the
+  // compiler waits as if the loads behind it had not been issued, i.e. for vmcnt(0..3): for the residual
+  // of two rounds ahead and for the stores of the round before)
   auto load_res = [&](int round) {
-    const int m = round >> 1, n = round & 1;
-    const int orow = r0 + 2 * n;
     ResPair rp = {{{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}}};
-    if (resp && ocol < wo && round < 6) {
+    if (RES && round < 6) {
+      const int m = round >> 1, n = round & 1;
+      const int oc = ocol < wo ? ocol : wo - 2;
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        const int co = cout0 + m * 32 + erow + 16 * j;
-        if (co < cout) {
+        int co = cout0 + m * 32 + erow + 16 * j;
+        co = co < cout ? co : cout - 1;
 #pragma unroll
-          for (int a2 = 0; a2 < 2; a2++)
-            if (orow + a2 < ho)
-              rp.v[j][a2] = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)(orow + a2) * ep.vres.rs + ocol);
+        for (int a2 = 0; a2 < 2; a2++) {
+          int rr = r0 + 2 * n + a2;
+          rr = rr < ho ? rr : ho - 1;
+          rp.v[j][a2] = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)rr * ep.vres.rs + oc);
         }
       }
     }
@@ -418,23 +477,23 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       const int orow = r0 + 2 * n;
       const ResPair rcur = rq[(m * 2 + n) & 1];
       rq[(m * 2 + n) & 1] = load_res(m * 2 + n + 2);
-#pragma unroll
-      for (int x = 0; x < XW; x++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          Es[((wave * XW + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[x][m][n][r];
+      // Es[xi][r][lane]: accumulator register r of lane (half, l31) = cout row (r & 3) + 8 (r >> 2) + 4 half
+      if (((m * 2 + n) & 1) == 0)
+        wino_store_round<0>(acc[0][m][n], acc[1][m][n], wave, lds0);
+      else
+        wino_store_round<1>(acc[0][m][n], acc[1][m][n], wave, lds0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (stores issued by hand: the compiler does not count them)
       __syncthreads();
-      if (!ep.d2w) {
+      if (!D2W) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int row = erow + 16 * j;
           float mm[16];
 #pragma unroll
-          for (int xi = 0; xi < 16; xi++) mm[xi] = Es[(xi * 32 + row) * 32 + ecol];
+          for (int xi = 0; xi < 16; xi++) mm[xi] = Es[xi * 1024 + ((row & 3) + 4 * (row >> 3)) * 64 + ((row >> 2) & 1) * 32 + ecol];
           const int co = cout0 + m * 32 + row;
           if (co < cout && ocol < wo) {
-            const float bco = ep.bias ? ep.bias[co] : 0.f;
-            const float sl = act == 1 ? ep.slope[co] : 0.f;
+            const float bco = ebias[m][j], sl = eslope[m][j];
             // Y = At M A, M[i][j] = mm[4 i + j]
             float ta[2][4];
 #pragma unroll
@@ -451,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
                 y0 = y0 < 0 ? y0 * sl : y0;
                 y1 = y1 < 0 ? y1 * sl : y1;
               }
-              if (resp) {
+              if (RES) {
                 y0 = rcur.v[j][a2].x + y0;
                 y1 = rcur.v[j][a2].y + y1;
               }
@@ -469,13 +528,14 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
         float m0[16], m1[16];
 #pragma unroll
         for (int xi = 0; xi < 16; xi++) {
-          m0[xi] = Es[(xi * 32 + 2 * erow) * 32 + ecol];
-          m1[xi] = Es[(xi * 32 + 2 * erow + 1) * 32 + ecol];
+          // rows 2 erow and 2 erow + 1: same (row >> 2), register index differs by one
+          const int ra = 2 * erow;
+          m0[xi] = Es[xi * 1024 + ((ra & 3) + 4 * (ra >> 3)) * 64 + ((ra >> 2) & 1) * 32 + ecol];
+          m1[xi] = Es[xi * 1024 + ((ra & 3) + 1 + 4 * (ra >> 3)) * 64 + ((ra >> 2) & 1) * 32 + ecol];
         }
         const int co = cout0 + m * 32 + 2 * erow;
         if (co < cout && ocol < wo) {
-          const float b0 = ep.bias ? ep.bias[co] : 0.f, b1 = ep.bias ? ep.bias[co + 1] : 0.f;
-          const float s0 = act == 1 ? ep.slope[co] : 0.f, s1 = act == 1 ? ep.slope[co + 1] : 0.f;
+          const float b0 = ebias[m][0], b1 = ebias[m][1], s0 = eslope[m][0], s1 = eslope[m][1];
           const int cq = co >> 2, sy = (co >> 1) & 1;
 #pragma unroll
           for (int a2 = 0; a2 < 2; a2++) {
@@ -569,23 +629,28 @@ extern "C" int pconv_conv3x3_wino(const float *in, const float *packed_u, const 
   const long long grid = (long long)tn * tiles_r * tiles_c * cblocks;
   PCONV_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_wino: grid %lld out of range", grid);
   const size_t smem = (size_t)kLdsFloats * sizeof(float);
+  // one instantiation per kind of layer: 0 plain, 1 residual, 2 depth-to-width
+  using kernel_t = decltype(&wino_conv3x3_kernel<false, false>);
+  static const kernel_t kernels[3] = {wino_conv3x3_kernel<false, false>, wino_conv3x3_kernel<true, false>,
+                                      wino_conv3x3_kernel<false, true>};
+  const int kind = d2w ? 2 : (residual ? 1 : 0);
   {
-    static std::atomic<unsigned long long> raised{0};
+    static std::atomic<unsigned long long> raised[3];
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) device = 0;
     const unsigned long long bit = 1ULL << (device & 63);
-    if (!(raised.load(std::memory_order_acquire) & bit)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv3x3_kernel),
+    if (!(raised[kind].load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernels[kind]),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) {
         pconv_set_error("conv3x3_wino: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e));
         return PCONV_ELAUNCH;
       }
-      raised.fetch_or(bit, std::memory_order_release);
+      raised[kind].fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL(wino_conv3x3_kernel, dim3((unsigned)grid), dim3(kThreads), smem, as_stream(stream), in, packed_u, out,
-                     cin, cin_pad, h, w, cout, ho, wo, tiles_r, tiles_c, cblocks, vin, vout, ep);
+  hipLaunchKernelGGL(kernels[kind], dim3((unsigned)grid), dim3(kThreads), smem, as_stream(stream), in, packed_u, out, cin,
+                     cin_pad, h, w, cout, ho, wo, tiles_r, tiles_c, cblocks, vin, vout, ep);
   PCONV_LAUNCH_CHECK("conv3x3_wino");
   return PCONV_OK;
 }

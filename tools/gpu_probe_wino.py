@@ -27,6 +27,8 @@ cases = [  # tn, cin, cout, rows (out), cols (out), residual+trim, d2w
     (128, 192, 192, 32, 1024, True, False), (16, 96, 96, 32, 1024, False, False), (128, 96, 96, 32, 1024, False, False),
     (16, 192, 768, 32, 1024, False, True), (128, 192, 768, 16, 512, False, True), (128, 192, 192, 16, 512, True, False),
 ]
+if os.environ.get("PCONV_PROBE_SHORT"):  # three shapes, Winograd only (kernel variants: PCONV_HIP_LIB)
+    cases = [cases[0], cases[4], cases[6]]
 for (tn, cin, cout, rows, cols, res, d2w) in cases:
     x = torch.randn(tn, cin, rows + 2, cols + 2, device=dev)
     conv = torch.nn.Conv2d(cin, cout, 3).to(dev)
