@@ -135,9 +135,12 @@ template <int MT, int NT, int WN, int EB = 16>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvEpilogue &ep, const float *inp,
                                               float *outp, const ConvView &vin, const ConvView &vout, int t, int r0,
                                               int c0, int cout0, int cout, int ho, int wo, int wm, int wn, int l31,
-                                              int half) {
-  const float *__restrict__ bias = ep.bias;
-  const float *__restrict__ slope = ep.slope;
+                                              int half, const float *bias_s, const float *slope_s) {
+  // bias_s / slope_s: the cout block's bias and PReLU slope in LDS (zeros where the layer has none), indexed
+  // by the cout inside the block.  Loaded from memory row by row, in front of their use, each load sat behind
+  // the store of the row before and each store behind that load (vmcnt counts both, and the compiler waits
+  // for vmcnt(0) around every guarded load): 2 x 16 x MT serial round trips per lane, ~75 of the ~95 us a
+  // 1x1 workgroup lived.
   const int32_t *__restrict__ col_limit = ep.col_limit;
   const int npart = ep.npart, act = ep.act;
   const int trim_at = ((ep.trim || act == 2 || act == 3) && col_limit) ? col_limit[t % npart] : wo;
@@ -153,8 +156,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
         const int r = 2 * rp;  // registers r, r+1: couts co (even), co+1 = sx 0, 1
         const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co >= cout) continue;
-        const float b0 = bias ? bias[co] : 0.f, b1 = bias ? bias[co + 1] : 0.f;
-        const float s0 = (act == 1) ? slope[co] : 0.f, s1 = (act == 1) ? slope[co + 1] : 0.f;
+        const float b0 = bias_s[co - cout0], b1 = bias_s[co - cout0 + 1];
+        const float s0 = slope_s[co - cout0], s1 = slope_s[co - cout0 + 1];
         const int cq = co >> 2, sy = (co >> 1) & 1;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
@@ -206,8 +209,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
         const int r = rb + rr;
         const int co = cout0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co >= cout) continue;
-        const float bco = bias ? bias[co] : 0.f;
-        const float sl = (act == 1) ? slope[co] : 0.f;
+        const float bco = bias_s[co - cout0], sl = slope_s[co - cout0];
 #pragma unroll
         for (int n = 0; n < NT; n++) {
           const int seg = wn * NT + n;
@@ -504,6 +506,14 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
   static_assert(C::STAGE * 4 <= 65536, "operand offsets of one buffer fit the 16-bit immediate");
   static_assert(kAhead * (MT + NT) <= 15, "lgkmcnt counts to 15");
 
+  // bias / PReLU slope of cout `tid` of the block: requested now, parked in LDS after the matrix loop
+  float my_bias = 0.f, my_slope = 0.f;
+  if (tid < C::BM) {
+    const int co = cout0 + tid < cout ? cout0 + tid : cout - 1;
+    if (ep.bias) my_bias = ep.bias[co];
+    if (ep.act == 1) my_slope = ep.slope[co];
+  }
+
   stager(0, 0).issue_all();
   __syncthreads();  // (also waits for the DMA: vmcnt(0))
 
@@ -526,11 +536,18 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
 #endif
   }
 
+  // (the barrier that ended the last chunk: nobody reads the stage memory any more)
+  static_assert(2 * C::BM <= C::STAGE && C::BM <= kThreads, "bias / slope table fits the stage memory");
+  if (tid < C::BM) {
+    lds[tid] = my_bias;
+    lds[C::BM + tid] = my_slope;
+  }
+  __syncthreads();
 #ifdef PCONV_ABL_NOEPI
   if (cin == -12345)
 #endif
   conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,
-                                                                                      cout, ho, wo, wm, wn, l31, half);
+                                                                                      cout, ho, wo, wm, wn, l31, half, lds, lds + C::BM);
 }
 
 // ---- weight-resident, register-blocked 1x1 convolution ---------------------------------
