@@ -61,9 +61,10 @@ constexpr int VSZ = 16 * KC * TX * TY;               // 4096: V[xi][ci][tile], d
 constexpr int USZ = KC * XW * CO;                    // 768: a wave's weight stage [ci][xi & 1][96]
 constexpr int URING = 4;                             // weight stages per wave
 constexpr int ULD = USZ / 4 / 64;                    // 3 16-byte DMA pieces per lane
-constexpr int kLdsFloats = PRING * PBUF + 2 * VSZ + kWaves * URING * USZ;  // 36864 floats = 144 KB
+constexpr int kStageFloats = PRING * PBUF + 2 * VSZ + kWaves * URING * USZ;  // 36864 floats = 144 KB
+constexpr int kLdsFloats = kStageFloats + 256;  // + the cout block's bias [128] and PReLU slope [128]
 constexpr int ESZ = 16 * 32 * 32;                    // one exchange round of the output transform
-static_assert(2 * ESZ <= kLdsFloats, "the two exchange buffers fit the stage memory");
+static_assert(2 * ESZ <= kStageFloats, "the two exchange buffers fit the stage memory");
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS of a CU");
 static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
 static_assert(USZ % 256 == 0, "weight stage = whole 16-byte DMA instructions");
@@ -335,6 +336,19 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
         for (int r = 0; r < 16; r++) acc[x][m][n][r] = 0.f;
 
   // ---- prologue ----
+  // bias / PReLU slope of the cout block -> a table behind the stage memory, by LDS-DMA with the first
+  // stages (waves 0-3: one 64-float piece each; couts past the end repeat the last one).  Loaded into
+  // registers in front of the way out they were one more exposed memory round trip per tile.
+  float *Bt = lds + kStageFloats;
+  if (wave < 4) {
+    const float *src = wave < 2 ? ep.bias : (ep.act == 1 ? ep.slope : nullptr);
+    int co = cout0 + (wave & 1) * 64 + lane;
+    co = co < cout ? co : cout - 1;
+    if (src)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + co), (lds_ptr_t *)(Bt + wave * 64), 4, 0, 0);
+    else
+      Bt[wave * 64 + lane] = 0.f;
+  }
   issue_patch(0, 0, true);
 #pragma unroll
   for (int k = 0; k < URING; k++) issue_weights(k, true);
@@ -403,19 +417,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   for (; c4 + 8 <= nchunk; c4 += 4) group(integral_constant<bool, true>{}, c4);
 #pragma unroll 1
   for (; c4 < nchunk; c4 += 4) group(integral_constant<bool, false>{}, c4);
-  // bias / PReLU slope of the thread's six couts (three 32-cout blocks x two), requested here: inside a
-  // round these loads sat behind the stores of the round before (vmcnt counts loads and stores)
   const int erow = wave * 2 + half, ecol = l31;  // cout inside the block (second pair: + 16; d2w: cout pair), tile column
-  float ebias[3][2], eslope[3][2];
-#pragma unroll
-  for (int m = 0; m < 3; m++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      int co = cout0 + m * 32 + (D2W ? 2 * erow + j : erow + 16 * j);
-      co = co < cout ? co : cout - 1;
-      ebias[m][j] = ep.bias ? ep.bias[co] : 0.f;
-      eslope[m][j] = ep.act == 1 ? ep.slope[co] : 0.f;
-    }
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
 #ifdef PCONV_WINO_ABL_NOEPILOGUE
   if (cin != -12345) {  // timing ablation: keep the accumulators alive, skip the way out
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
           for (int xi = 0; xi < 16; xi++) mm[xi] = Es[xi * 1024 + ((row & 3) + 4 * (row >> 3)) * 64 + ((row >> 2) & 1) * 32 + ecol];
           const int co = cout0 + m * 32 + row;
           if (co < cout && ocol < wo) {
-            const float bco = ebias[m][j], sl = eslope[m][j];
+            const float bco = Bt[m * 32 + row], sl = Bt[128 + m * 32 + row];
             // Y = At M A, M[i][j] = mm[4 i + j]
             float ta[2][4];
 #pragma unroll
@@ -535,7 +537,8 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
         }
         const int co = cout0 + m * 32 + 2 * erow;
         if (co < cout && ocol < wo) {
-          const float b0 = ebias[m][0], b1 = ebias[m][1], s0 = eslope[m][0], s1 = eslope[m][1];
+          const float b0 = Bt[m * 32 + 2 * erow], b1 = Bt[m * 32 + 2 * erow + 1];
+          const float s0 = Bt[128 + m * 32 + 2 * erow], s1 = Bt[128 + m * 32 + 2 * erow + 1];
           const int cq = co >> 2, sy = (co >> 1) & 1;
 #pragma unroll
           for (int a2 = 0; a2 < 2; a2++) {
