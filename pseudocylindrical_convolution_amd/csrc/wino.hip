@@ -40,6 +40,16 @@
 
 namespace {
 
+#ifdef PCONV_WINO_STAMP
+// profiling build (tools/gpu_probe_wino_stamps.py): cycles (s_memtime) the waves of one workgroup spend in
+// the phases of a steady-state chunk: [wave][barrier wait, head (patch DMA issue), matrix block, weight DMA
+// issue, -, chunks]
+__device__ unsigned long long wino_stamps[8][6];
+#define WINO_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define WINO_STAMP(var)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -151,20 +161,94 @@ __device__ __forceinline__ void wino_read_step(float (&a)[3], float (&b)[2], uns
   b[1] = wino_lds_read<boff + 128>(bbase);
 }
 
+// Half of the input transform V = Bt d B of a (channel, tile) pair -- two of the four rows of Bt d
+// (d0 - d2, d1 + d2 | d2 - d1, d1 - d3) and their columns -- in three pieces that the matrix block below
+// places between its MFMAs.  Which half is a property of the wave: row offsets rp / rq / rs (floats) and the
+// sign sg are wave-uniform, so that every wave runs the same instructions:
+//   first row = d[rp] - d[rq], second row = d[1] + sg * d[rs]   (an exact product: the same bits as d1 +- d)
+struct WinoHalf {
+  const float *tp;  // the pair's 4 x 4 block in patch stage 0 (row pitch PC)
+  float *tv;        // slot of the half's first value in V buffer 0: V[xi][ci][tile], xi = 8 * half ..
+  int rp, rq, rs;
+  float sg;
+};
+struct WinoRows {
+  f32x2 p[2], q[2], r[2], s[2];
+};
+template <int PB>
+__device__ __forceinline__ void wino_half_load(const WinoHalf &h, WinoRows &w) {
+  const float *t = h.tp + PB * PBUF;
+  w.p[0] = *reinterpret_cast<const f32x2 *>(t + h.rp), w.p[1] = *reinterpret_cast<const f32x2 *>(t + h.rp + 2);
+  w.q[0] = *reinterpret_cast<const f32x2 *>(t + h.rq), w.q[1] = *reinterpret_cast<const f32x2 *>(t + h.rq + 2);
+  w.r[0] = *reinterpret_cast<const f32x2 *>(t + PC), w.r[1] = *reinterpret_cast<const f32x2 *>(t + PC + 2);
+  w.s[0] = *reinterpret_cast<const f32x2 *>(t + h.rs), w.s[1] = *reinterpret_cast<const f32x2 *>(t + h.rs + 2);
+}
+// row J (0 / 1) of the half: its four columns (t0 - t2, t1 + t2, t2 - t1, t1 - t3)
+template <int J>
+__device__ __forceinline__ void wino_half_math(const WinoHalf &h, const WinoRows &w, float (&o)[4]) {
+  float t[4];
+  if (J == 0) {
+    t[0] = w.p[0].x - w.q[0].x, t[1] = w.p[0].y - w.q[0].y, t[2] = w.p[1].x - w.q[1].x, t[3] = w.p[1].y - w.q[1].y;
+  } else {
+    t[0] = __builtin_fmaf(h.sg, w.s[0].x, w.r[0].x), t[1] = __builtin_fmaf(h.sg, w.s[0].y, w.r[0].y);
+    t[2] = __builtin_fmaf(h.sg, w.s[1].x, w.r[1].x), t[3] = __builtin_fmaf(h.sg, w.s[1].y, w.r[1].y);
+  }
+  o[0] = t[0] - t[2], o[1] = t[1] + t[2], o[2] = t[2] - t[1], o[3] = t[1] - t[3];
+}
+template <int VBUF, int J>
+__device__ __forceinline__ void wino_half_store(const WinoHalf &h, const float (&o)[4]) {
+  constexpr int XS = KC * TX * TY;
+  float *v = h.tv + VBUF * VSZ + J * 4 * XS;
+#pragma unroll
+  for (int j = 0; j < 4; j++) v[j * XS] = o[j];
+}
+
+// The matrix block of a chunk: four steps (GEMM x, k-pair kp) of six MFMAs, operands of step s+1 read before
+// the MFMAs of step s.  Between its MFMAs the wave transforms ITS half of a (channel, tile) pair of the next
+// chunk: a vector or LDS instruction costs nothing in the shadow of the wave's own matrix instruction, while
+// in front of the block (this kernel's first form: waves 0-3 transformed, then multiplied) the same
+// instructions were issued one per matrix instruction of the SIMD partner -- ~2 000 cycles for 37
+// instructions (in-kernel stamps, profiles/round3_wino_stamps.txt) -- and the partner then waited at the
+// barrier for the late wave's matrix block: the two waves of a SIMD took turns instead of sharing the pipe.
 template <int U, int VB, int ST>
 __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&a)[2][3], float (&b)[2][2], unsigned abase,
-                                               unsigned bbase) {
+                                               unsigned bbase, const WinoHalf &h, WinoRows &rows) {
   constexpr int NST = 2 * XW;
+  constexpr int X = ST >> 1, S = ST & 1;
+  static_assert(NST == 4, "the transform pieces are placed by hand in four steps");
   if constexpr (ST + 1 < NST) wino_read_step<U, VB, ST + 1>(a[(ST + 1) & 1], b[(ST + 1) & 1], abase, bbase);
-  wino_wait<(ST + 1 < NST) ? 5 : 0>(a[ST & 1], b[ST & 1]);
+  wino_wait<(ST + 1 < NST) ? 5 : 0>(a[S], b[S]);
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int m = 0; m < 3; m++)
-#pragma unroll
-    for (int n = 0; n < 2; n++)
-      acc[ST >> 1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ST & 1][m], b[ST & 1][n], acc[ST >> 1][m][n], 0, 0, 0);
+  float o[4];
+  acc[X][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][0], b[S][0], acc[X][0][0], 0, 0, 0);
+#ifndef PCONV_WINO_ABL_NOTRANSFORM
+  if constexpr (ST == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    wino_half_load<VB ^ 1>(h, rows);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+  acc[X][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][0], b[S][1], acc[X][0][1], 0, 0, 0);
+  acc[X][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][1], b[S][0], acc[X][1][0], 0, 0, 0);
+#ifndef PCONV_WINO_ABL_NOTRANSFORM
+  if constexpr (ST == 1 || ST == 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    wino_half_math<ST - 1>(h, rows, o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+  acc[X][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][1], b[S][1], acc[X][1][1], 0, 0, 0);
+  acc[X][2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][2], b[S][0], acc[X][2][0], 0, 0, 0);
+#ifndef PCONV_WINO_ABL_NOTRANSFORM
+  if constexpr (ST == 1 || ST == 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    wino_half_store<VB ^ 1, ST - 1>(h, o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+  acc[X][2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][2], b[S][1], acc[X][2][1], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1>(acc, a, b, abase, bbase);
+  if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1>(acc, a, b, abase, bbase, h, rows);
 }
 
 // Eight accumulator registers -> LDS by `ds_write_addtid_b32` (address = M0 + offset + 4 * lane: no address
@@ -294,22 +378,25 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + j * 256 + lo), (lds_ptr_t *)(dst + j * 256), 16, 0, 0);
   };
 
-  // ---- input transform: V = Bt d B.  Waves 0-3 (one per SIMD) do it: wave -> channel of the stage, lane ->
-  // tile, all sixteen V values of the (channel, tile) pair per thread: 8 LDS reads, 32 adds, 16 LDS writes.
-  // (Spread over all eight waves -- one half of V per thread -- the shared rows were read and combined twice:
-  // 2 x (6 reads + 28 adds + 8 writes); 214 -> 227 TFLOP/s.)  Rows of Bt d: d0 - d2, d1 + d2, d2 - d1, d1 - d3.
-  // The transform waves run it BEFORE their matrix block: their SIMD partner (wave + 4) is on the matrix pipe.
-  const bool early = wave < 4;  // (uniform)
+  // ---- input transform: V = Bt d B.  wave -> channel (wave & 3) of the stage, lane -> tile; waves 0-3 take
+  // the first two rows of Bt d (V values xi = 0..7 of the pair), waves 4-7 the other two: 8 LDS reads, 8 + 8
+  // adds, 8 LDS writes per thread and chunk, placed between the MFMAs of the chunk before (wino_mma_steps).
+  // transform_full is the same arithmetic for a whole pair, in one piece: stage 0, by waves 0-3.
+  const int wave4 = wave >> 2, tch = wave & 3;  // (uniform)
   const int tty = lane >> 5, ttx = lane & 31;
+  const float *tp0 = Ps + (tch * PR + 2 * tty) * PC + 2 * ttx;  // the pair's 4 x 4 block in patch stage 0
+  float *tv0 = Vs + tch * (TX * TY) + lane;                     // its slot in V buffer 0
+  const WinoHalf half_t = {tp0, tv0 + wave4 * 8 * (KC * TX * TY), wave4 ? 2 * PC : 0, wave4 ? PC : 2 * PC,
+                           wave4 ? 3 * PC : 2 * PC, wave4 ? -1.f : 1.f};
   auto transform_full = [&](int pbuf, int vbuf) {
-    const float *p = Ps + pbuf * PBUF + (wave * PR + 2 * tty) * PC + 2 * ttx;
+    const float *p = tp0 + pbuf * PBUF;
     float d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const f32x2 lo = *reinterpret_cast<const f32x2 *>(p + r * PC), hi = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
       d[r][0] = lo.x, d[r][1] = lo.y, d[r][2] = hi.x, d[r][3] = hi.y;
     }
-    float *v = Vs + vbuf * VSZ + wave * (TX * TY) + lane;
+    float *v = tv0 + vbuf * VSZ;
     constexpr int XS = KC * TX * TY;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -355,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   issue_patch(1, 1, true);
   __builtin_amdgcn_s_waitcnt(0);  // (vmcnt(0) among others)
   __syncthreads();
-  if (early) transform_full(0, 0);
+  if (wave4 == 0) transform_full(0, 0);
 
   // per-lane LDS byte addresses of the operand fragments (see wino_read_step): A = weights
   // [stage][ci = 2 kp + half][x][96], B = V[vbuf][xi = 2 wave + x][ci = 2 kp + half][tile]
@@ -371,10 +458,14 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   // complete (lgkmcnt(0): this thread's LDS writes) and the MFMAs of chunk-1, last readers of V's other
   // buffer, are done.  Wait and barrier are one asm statement: __syncthreads() would wait for vmcnt(0).
   // STEADY = every stream is still issuing (chunk + 4 < nchunk, chunk > 0): no guards, counted wait.
+#ifdef PCONV_WINO_STAMP
+  unsigned long long st_bar = 0, st_head = 0, st_mm = 0, st_wd = 0, st_n = 0;
+#endif
   auto body = [&](auto u_c, auto steady_c, int chunk) {
     constexpr int U = decltype(u_c)::value;
     constexpr bool STEADY = decltype(steady_c)::value;
     constexpr int vb = U & 1;
+    WINO_STAMP(t0);
 #ifdef PCONV_WINO_ABL_NOBAR
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
@@ -383,20 +474,22 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-    const bool more = STEADY || chunk + 1 < nchunk;
-#ifndef PCONV_WINO_ABL_NOTRANSFORM
-    // waves 0-3: V(chunk+1) from patch(chunk+1), before their matrix block (see transform_full)
-    if (more && early) transform_full(vb ^ 1, vb ^ 1);
-#endif
-    issue_patch(chunk + 2, vb, !STEADY);  // (that stage was read by transform(chunk), before the barrier)
-    // four steps (GEMM x, k-pair kp), operands of step s+1 read before the MFMAs of step s
+    WINO_STAMP(t1);
+    issue_patch(chunk + 2, vb, !STEADY);  // (that stage was read by the transform of this chunk, before the barrier)
+    WINO_STAMP(t2);
+    // the matrix block, with this wave's half of the transform patch(chunk+1) -> V(chunk+1) inside (behind
+    // the last chunk it turns stale patch bytes into V values nobody reads)
     float a[2][3], bv[2][2];
+    WinoRows rows;
     wino_read_step<U, vb, 0>(a[0], bv[0], abase, bbase);
-    wino_mma_steps<U, vb, 0>(acc, a, bv, abase, bbase);
+    wino_mma_steps<U, vb, 0>(acc, a, bv, abase, bbase, half_t, rows);
+    WINO_STAMP(t3);
     // this wave's reads of the weight stage are complete (their values fed the MFMAs): refill it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     issue_weights(chunk + URING, !STEADY);
-#ifndef PCONV_WINO_ABL_NOTRANSFORM
+#ifdef PCONV_WINO_STAMP
+    WINO_STAMP(t4);
+    if (STEADY) st_bar += t1 - t0, st_head += t2 - t1, st_mm += t3 - t2, st_wd += t4 - t3, st_n += 1;
 #endif
   };
   using std::integral_constant;
@@ -418,6 +511,12 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #pragma unroll 1
   for (; c4 < nchunk; c4 += 4) group(integral_constant<bool, false>{}, c4);
   const int erow = wave * 2 + half, ecol = l31;  // cout inside the block (second pair: + 16; d2w: cout pair), tile column
+#ifdef PCONV_WINO_STAMP
+  if (blockIdx.x == gridDim.x / 2 + 1 && lane == 0) {
+    unsigned long long *o = wino_stamps[wave];
+    o[0] = st_bar, o[1] = st_head, o[2] = st_mm, o[3] = st_wd, o[4] = 0, o[5] = st_n;
+  }
+#endif
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
 #ifdef PCONV_WINO_ABL_NOEPILOGUE
   if (cin != -12345) {  // timing ablation: keep the accumulators alive, skip the way out
@@ -576,6 +675,12 @@ inline bool view_ok(const WView &v, int c, int h, int w) {
 }
 
 }  // namespace
+
+#ifdef PCONV_WINO_STAMP
+extern "C" int pconv_wino_read_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(wino_stamps), sizeof(wino_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // floats of the packed Winograd weights of a (cout, cin, 3, 3) layer
 extern "C" long long pconv_wino_packed_size(int cout, int cin) {
