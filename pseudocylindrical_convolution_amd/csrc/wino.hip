@@ -54,6 +54,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void glb_ptr_t;
+typedef const __attribute__((address_space(1))) char glb_bytes_t;
 
 constexpr int kThreads = 512, kWaves = 8;
 constexpr int XW = 2;                                // GEMMs (xi) per wave
@@ -79,6 +80,7 @@ static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS of a CU");
 static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
 static_assert(USZ % 256 == 0, "weight stage = whole 16-byte DMA instructions");
 static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
+static_assert(PLD <= 4 && ULD <= 4, "DMA pieces of a chunk fit the gaps of one step of the matrix block");
 static_assert(URING == 4 && PRING == 2, "the main loop is unrolled over four chunks: ring slots are compile-time");
 static_assert(XW == 2, "the way out stores a wave's two GEMMs by hand");
 static_assert(KC == 4 && kWaves * XW == 16, "transform: waves 0-3 take one channel of the stage each; two GEMMs per wave");
@@ -210,9 +212,12 @@ __device__ __forceinline__ void wino_half_store(const WinoHalf &h, const float (
 // instructions were issued one per matrix instruction of the SIMD partner -- ~2 000 cycles for 37
 // instructions (in-kernel stamps, profiles/round3_wino_stamps.txt) -- and the partner then waited at the
 // barrier for the late wave's matrix block: the two waves of a SIMD took turns instead of sharing the pipe.
-template <int U, int VB, int ST>
+// IL: the chunk's DMA instructions sit there too, one per gap -- the patch pieces (`pd(j)`) in step 0, the
+// weight pieces (`wd(j)`: the stage this block reads, free once the operands of its last step have landed)
+// in step 3; issued in front of / behind the block they ran while neither wave of the SIMD had an MFMA ready.
+template <int U, int VB, int ST, bool IL, class PD, class WD>
 __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&a)[2][3], float (&b)[2][2], unsigned abase,
-                                               unsigned bbase, const WinoHalf &h, WinoRows &rows) {
+                                               unsigned bbase, const WinoHalf &h, WinoRows &rows, PD &pd, WD &wd) {
   constexpr int NST = 2 * XW;
   constexpr int X = ST >> 1, S = ST & 1;
   static_assert(NST == 4, "the transform pieces are placed by hand in four steps");
@@ -228,7 +233,23 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
+  auto dma = [&](auto j_c) {  // DMA piece j of this step, if it has one
+    constexpr int J = decltype(j_c)::value;
+    if constexpr (IL && ST == 0 && J < PLD) {
+      __builtin_amdgcn_sched_barrier(0);
+      pd(j_c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (IL && ST == NST - 1 && J < ULD) {
+      __builtin_amdgcn_sched_barrier(0);
+      wd(j_c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using std::integral_constant;
+  dma(integral_constant<int, 0>{});
   acc[X][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][0], b[S][1], acc[X][0][1], 0, 0, 0);
+  dma(integral_constant<int, 1>{});
   acc[X][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][1], b[S][0], acc[X][1][0], 0, 0, 0);
 #ifndef PCONV_WINO_ABL_NOTRANSFORM
   if constexpr (ST == 1 || ST == 2) {
@@ -237,7 +258,9 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
+  dma(integral_constant<int, 2>{});
   acc[X][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][1], b[S][1], acc[X][1][1], 0, 0, 0);
+  dma(integral_constant<int, 3>{});
   acc[X][2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][2], b[S][0], acc[X][2][0], 0, 0, 0);
 #ifndef PCONV_WINO_ABL_NOTRANSFORM
   if constexpr (ST == 1 || ST == 2) {
@@ -248,7 +271,7 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
 #endif
   acc[X][2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][2], b[S][1], acc[X][2][1], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1>(acc, a, b, abase, bbase, h, rows);
+  if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1, IL>(acc, a, b, abase, bbase, h, rows, pd, wd);
 }
 
 // Eight accumulator registers -> LDS by `ds_write_addtid_b32` (address = M0 + offset + 4 * lane: no address
@@ -341,41 +364,51 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     int ir = r0 + pr, ic = c0 + pc;
     ir = ir < h ? ir : h - 1;
     ic = ic < w ? ic : w - 1;
-    xoffs[j] = (unsigned)((long long)ci * vin.cs + (long long)ir * vin.rs + ic);
+    xoffs[j] = (unsigned)(((long long)ci * vin.cs + (long long)ir * vin.rs + ic) * 4);  // bytes
   }
   const size_t xstep = (size_t)KC * vin.cs;
+  // (one DMA instruction: the steady-state chunk places them one by one between its MFMAs)
+  auto patch_piece = [&](int chunk, int buf, int j) {  // (elements past PSZ re-read element 0 into the buffer's slack)
+    // (uniform base + 32-bit byte offset of the lane: `global_load_lds_dword v, s[..]`, no 64-bit address
+    // arithmetic in front of the DMA -- every instruction here costs the matrix pipe its issue time)
+    unsigned xo = xoffs[j];
+    asm volatile("" : "+v"(xo));
+    glb_bytes_t *xb = (glb_bytes_t *)(inp + chunk * xstep);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + xo), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4, 0,
+                                     0);
+  };
   auto issue_patch = [&](int chunk, int buf, bool guard) {
     if (guard && chunk >= nchunk) return;
 #ifdef PCONV_WINO_ABL_NOPDMA
     if (chunk >= PRING) return;
 #endif
-    const float *xb = inp + chunk * xstep;
 #pragma unroll
-    for (int j = 0; j < PLD; j++) {  // (elements past PSZ re-read element 0 into the buffer's slack)
-      unsigned xo = xoffs[j];
-      asm volatile("" : "+v"(xo));
-      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + xo), (lds_ptr_t *)(Ps + buf * PBUF + j * kThreads + wave * 64), 4, 0,
-                                       0);
-    }
+    for (int j = 0; j < PLD; j++) patch_piece(chunk, buf, j);
   };
   // a weight stage = KC channels x the wave's two GEMMs x 96 floats = 3 KB contiguous in the packed
   // weights: three 16-byte LDS-DMA instructions
   const float *uw = upk + ((size_t)cb * kWaves + wave) * cin_pad * XW * CO;  // wave-uniform (scalar registers)
   float *us_w = Us + wave * URING * USZ;
+  auto weight_piece = [&](int chunk, auto j_c) {
+    constexpr int j = decltype(j_c)::value;
+    glb_bytes_t *src = (glb_bytes_t *)(uw + (size_t)chunk * USZ);  // (uniform)
+    float *dst = us_w + (chunk % URING) * USZ;
+    // (opaque lane offset: hoisted out of the loop as a 64-bit per-lane pointer it costs two registers
+    // the matrix loop does not have -- a spill there reloads through vmcnt, i.e. waits for every DMA)
+    unsigned lo = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lo));
+    // (the instruction's immediate offset moves both ends: piece j of the stage, in memory and in LDS)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + lo), (lds_ptr_t *)dst, 16, j * 1024, 0);
+  };
   auto issue_weights = [&](int chunk, bool guard) {
     if (guard && chunk >= nchunk) return;
 #ifdef PCONV_WINO_ABL_NOWDMA
     if (chunk >= URING) return;
 #endif
-    const float *src = uw + (size_t)chunk * USZ;
-    float *dst = us_w + (chunk % URING) * USZ;
-    // (opaque lane offset: hoisted out of the loop as a 64-bit per-lane pointer it costs two registers
-    // the matrix loop does not have -- a spill there reloads through vmcnt, i.e. waits for every DMA)
-    unsigned lo = (unsigned)lane * 4u;
-    asm volatile("" : "+v"(lo));
-#pragma unroll
-    for (int j = 0; j < ULD; j++)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + j * 256 + lo), (lds_ptr_t *)(dst + j * 256), 16, 0, 0);
+    static_assert(ULD == 3, "weight pieces are issued by name");
+    weight_piece(chunk, std::integral_constant<int, 0>{});
+    weight_piece(chunk, std::integral_constant<int, 1>{});
+    weight_piece(chunk, std::integral_constant<int, 2>{});
   };
 
   // ---- input transform: V = Bt d B.  wave -> channel (wave & 3) of the stage, lane -> tile; waves 0-3 take
@@ -469,24 +502,41 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #ifdef PCONV_WINO_ABL_NOBAR
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
+#ifdef PCONV_WINO_ABL_NOWDMA
+    if (STEADY)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     if (STEADY)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ULD) : "memory");
+#endif
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     WINO_STAMP(t1);
-    issue_patch(chunk + 2, vb, !STEADY);  // (that stage was read by the transform of this chunk, before the barrier)
+    // steady state: the DMA instructions go inside the matrix block; head and tail chunks, where a stream may
+    // have ended, keep them around it (a guard inside the block would be a join with 192 live accumulators)
+    if (!STEADY) issue_patch(chunk + 2, vb, true);  // (that stage was read by the transform of this chunk, before the barrier)
     WINO_STAMP(t2);
     // the matrix block, with this wave's half of the transform patch(chunk+1) -> V(chunk+1) inside (behind
     // the last chunk it turns stale patch bytes into V values nobody reads)
     float a[2][3], bv[2][2];
     WinoRows rows;
     wino_read_step<U, vb, 0>(a[0], bv[0], abase, bbase);
-    wino_mma_steps<U, vb, 0>(acc, a, bv, abase, bbase, half_t, rows);
+#ifdef PCONV_WINO_ABL_NOPDMA
+    auto pd = [&](auto) {};
+#else
+    auto pd = [&](auto j_c) { patch_piece(chunk + 2, vb, decltype(j_c)::value); };
+#endif
+#ifdef PCONV_WINO_ABL_NOWDMA
+    auto wd = [&](auto) {};
+#else
+    auto wd = [&](auto j_c) { weight_piece(chunk + URING, j_c); };
+#endif
+    wino_mma_steps<U, vb, 0, STEADY>(acc, a, bv, abase, bbase, half_t, rows, pd, wd);
     WINO_STAMP(t3);
-    // this wave's reads of the weight stage are complete (their values fed the MFMAs): refill it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    issue_weights(chunk + URING, !STEADY);
+    // (this wave's reads of the weight stage are complete -- their values fed the MFMAs: refill it)
+    if (!STEADY) issue_weights(chunk + URING, true);
 #ifdef PCONV_WINO_STAMP
     WINO_STAMP(t4);
     if (STEADY) st_bar += t1 - t0, st_head += t2 - t1, st_mm += t3 - t2, st_wd += t4 - t3, st_n += 1;
@@ -724,8 +774,8 @@ extern "C" int pconv_conv3x3_wino(const float *in, const float *packed_u, const 
   const WEpilogue ep = {bias, slope, residual, col_limit, npart, act, trim, d2w, view_at(views, 2, cout, ho, wo)};
   PCONV_REQUIRE(view_ok(vin, cin, h, w) && view_ok(vout, oc, oh, ow) && (!residual || view_ok(ep.vres, cout, ho, wo)),
                 "conv3x3_wino: strides overlap");
-  PCONV_REQUIRE((long long)(KC - 1) * vin.cs + (long long)(h - 1) * vin.rs + w < (1LL << 32),
-                "conv3x3_wino: input channel stride too large for 32-bit chunk offsets");
+  PCONV_REQUIRE(((long long)(KC - 1) * vin.cs + (long long)(h - 1) * vin.rs + w) * 4 < (1LL << 32),
+                "conv3x3_wino: input channel stride too large for 32-bit byte offsets inside a chunk");
   // float2 / float4 accesses: rows of every view start on even element offsets
   PCONV_REQUIRE(vout.rs % 2 == 0 && vout.cs % 2 == 0 && vout.ts % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
                 "conv3x3_wino: output rows must be 8-byte aligned");
