@@ -240,6 +240,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void glb_ptr_t;
+typedef const __attribute__((address_space(1))) char glb_bytes_t;
 
 // LDS-DMA of one chunk (input patch + weight slab): XLD patch dwords, then WLD weight float4s per
 // thread, all issued at the head of the previous chunk's matrix loop.  (Issuing them one piece every
@@ -265,15 +266,18 @@ struct ConvStager {
 #endif
       const int e = tid + J * C::THREADS;
       if (e < C::XSZ) {
-        unsigned off = xoffs[J];
+        unsigned off = xoffs[J];  // bytes
         if (ragged) {
           // channels past cin: read the last real one instead -- their rows of the
           // packed weight are zero, so the product adds +0 to the chain
           const int ci = e / (P::PC * P::PR);
-          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * cs);
+          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * cs * 4);
         }
-        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(xb + off), (lds_ptr_t *)(xs + J * C::THREADS + wave * 64), 4, 0,
-                                         0);
+        // (uniform base + 32-bit byte offset of the lane: `global_load_lds_dword v, s[..]`, no 64-bit vector
+        // add in front of the DMA)
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)((glb_bytes_t *)xb + off),
+                                         (lds_ptr_t *)(xs + J * C::THREADS + wave * 64), 4, 0, 0);
       }
     } else {
 #ifdef PCONV_ABL_NOWDMA
@@ -281,9 +285,12 @@ struct ConvStager {
 #endif
       constexpr int JW = J - C::XLD;
       const int e4 = tid + JW * C::THREADS;
-      if (e4 < C::WSZ / 4)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wb + woffs[JW]),
+      if (e4 < C::WSZ / 4) {
+        unsigned off = woffs[JW];  // bytes
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)((glb_bytes_t *)wb + off),
                                          (lds_ptr_t *)(ws + (JW * C::THREADS + wave * 64) * 4), 16, 0, 0);
+      }
     }
   }
 
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: LDS-DMA bases stay in scalar registers)
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
 
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
     int ic = c0 * S + pc * P::PS;
     ir = ir < h ? ir : h - 1;
     ic = ic < w ? ic : w - 1;
-    xoffs[j] = (unsigned)(ci * vin.cs + (long long)ir * vin.rs + ic);
+    xoffs[j] = (unsigned)((ci * vin.cs + (long long)ir * vin.rs + ic) * 4);  // bytes
   }
 #pragma unroll
   for (int j = 0; j < C::WLD; j++) {
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
     e4 = e4 < C::WSZ / 4 ? e4 : 0;
     const int kk = e4 / (C::BM / 4);
     const int co = (e4 % (C::BM / 4)) * 4;
-    woffs[j] = (unsigned)(kk * cout_pad + co);
+    woffs[j] = (unsigned)(kk * cout_pad + co) * 4u;  // bytes
   }
   const int tail = cin % KC;  // channels of a ragged last chunk (0: none)
   const size_t xstep = (size_t)KC * vin.cs, wstep = (size_t)C::KK * cout_pad;
@@ -977,8 +984,8 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
   PCONV_REQUIRE(view_ok(vin, cin, h, w) && view_ok(vout, oc, oh, ow) &&
                     (!residual || view_ok(ep.vres, cout, ho, wo)) && (!gate || view_ok(ep.vgate, cout, ho, wo)),
                 "conv2d: strides overlap");
-  PCONV_REQUIRE((long long)(16 - 1) * vin.cs + (long long)(h - 1) * vin.rs + w < (1LL << 32),
-                "conv2d: input channel stride too large for 32-bit chunk offsets");
+  PCONV_REQUIRE(((long long)(16 - 1) * vin.cs + (long long)(h - 1) * vin.rs + w) * 4 < (1LL << 32),
+                "conv2d: input channel stride too large for 32-bit byte offsets inside a chunk");
   int rc;
 #define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, vin, vout, ep, s
   // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):
