@@ -586,7 +586,10 @@ __device__ __forceinline__ float4 load4_base_off(global_bytes *base, unsigned of
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <int WM, bool SQ>
+// RES: the layer adds a residual.  The kernel takes the epilogues of the codec's big 1x1 layers: bias, PReLU
+// (`act` 0 = PReLU with slope 1: v * 1 is v), the GDN pair (SQ), residual, trim; gates, the sigmoid and the
+// depth-to-width store stay with the tiled kernel.
+template <int WM, bool SQ, bool RES>
 __global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int kpad, int h, int w,
     int cout, int cout_pad, int tiles_r, int tiles_c, int cblocks, int passes, int stagger, ConvView vin,
@@ -622,8 +625,16 @@ __global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)(wp + (size_t)kk * cout_pad + cout0 + co),
                                        (lds_ptr_t *)(lds + (size_t)(e4 - lane) * 4), 16, 0, 0);
     }
+    // bias and PReLU slope of the cout block, behind the slab (see conv_epilogue: loaded row by row in
+    // front of their use they sat behind the previous row's store)
+    if (tid < BM) {
+      const int co = cout0 + tid < cout ? cout0 + tid : cout - 1;
+      lds[kpad * BM + tid] = ep.bias ? ep.bias[co] : 0.f;
+      lds[kpad * BM + BM + tid] = ep.act == 1 ? ep.slope[co] : 1.f;
+    }
     __syncthreads();  // (waits for the DMA: vmcnt(0)); the only barrier of the kernel
   }
+  const float *bias_s = lds + kpad * BM, *slope_s = bias_s + BM;
   if (gc0 >= w) return;  // the group lies past the right edge of the tensor
   const int KP = kpad / 2;
   const size_t kstep = (size_t)2 * vin.cs * sizeof(float);
@@ -656,10 +667,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
         if (co >= cout) break;
         for (int j = 0; j < 2; j++) {
           if (c2 + j >= w) continue;
-          if (ep.d2w)
-            outp[(size_t)(co >> 2) * vout.cs + (size_t)(2 * orow + ((co >> 1) & 1)) * vout.rs + 2 * (c2 + j) + (co & 1)] = 0.f;
-          else
-            outp[(size_t)co * vout.cs + (size_t)orow * vout.rs + c2 + j] = 0.f;
+          outp[(size_t)co * vout.cs + (size_t)orow * vout.rs + c2 + j] = 0.f;
         }
       }
       continue;
@@ -718,84 +726,81 @@ __global__ __launch_bounds__(512, 2) void conv1x1_rb_kernel(
         }
       }
     }
-    // ---- way out (ConvEpilogue), 4 consecutive pixels of one cout row per step ----
+    // ---- way out: 4 consecutive pixels of one cout row per step, 48 rows per lane ----
+    // What a row reads from memory (the residual, the GDN's own input) is requested a batch of rows
+    // ahead, with addresses clamped into the tensor instead of guards around the loads: straight-line
+    // code, so the compiler counts the loads and the stores (vmcnt(n)) and a batch's wait leaves the next
+    // batch and the stores of the one before in flight.  (Loaded row by row in front of their use, behind
+    // a guard, every row was load -> vmcnt(0) -> store: 48 serial round trips per pass.)
     const int act = ep.act;
     const int trim_at = ((ep.trim || act == 2 || act == 3) && ep.col_limit) ? limit : dead_at;
-    const float *resp = ep.residual ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
-    const float *gatep = ep.gate ? ep.gate + (size_t)t * ep.vgate.ts : nullptr;
+    const float *resp = RES ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+    constexpr int NROW = MT * 16, EB = (SQ && RES) ? 1 : 4, NB = NROW / EB;
+    struct RowIn {
+      float4 r, x;
+    };
+    auto row_cout = [&](int q) { return cbase + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * half; };
+    auto request = [&](int q) {
+      RowIn v = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      int co = row_cout(q);
+      co = co < cout ? co : cout - 1;
+      if (RES) v.r = *reinterpret_cast<const float4 *>(resp + (size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + col);
+      if (SQ) v.x = *reinterpret_cast<const float4 *>(inp + (size_t)co * vin.cs + (size_t)orow * vin.rs + col);
+      return v;
+    };
+    RowIn cur[EB], nxt[EB];
+    if (RES || SQ) {
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
+      for (int e = 0; e < EB; e++) cur[e] = request(e);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        if (ep.d2w && (r & 1)) continue;  // d2w stores the (r, r+1) cout pair together
-        const int co = cbase + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= cout) continue;
-        if (ep.d2w) {
-          // couts co (sx = 0) and co + 1 (sx = 1) of 4 pixels -> 8 consecutive outputs
-          const float b0 = ep.bias ? ep.bias[co] : 0.f, b1 = ep.bias ? ep.bias[co + 1] : 0.f;
-          const float s0 = (act == 1) ? ep.slope[co] : 0.f, s1 = (act == 1) ? ep.slope[co + 1] : 0.f;
-          float v0[4] = {acc[m][0][r] + b0, acc[m][1][r] + b0, acc[m][2][r] + b0, acc[m][3][r] + b0};
-          float v1[4] = {acc[m][0][r + 1] + b1, acc[m][1][r + 1] + b1, acc[m][2][r + 1] + b1, acc[m][3][r + 1] + b1};
-          if (act == 1) {
+    for (int bi = 0; bi < NB; bi++) {
+      if ((RES || SQ) && bi + 1 < NB) {
+#pragma unroll
+        for (int e = 0; e < EB; e++) nxt[e] = request((bi + 1) * EB + e);
+      }
+#pragma unroll
+      for (int e = 0; e < EB; e++) {
+        const int q = bi * EB + e, m = q >> 4, r = q & 15;
+        const int co = row_cout(q);
+        if (co < cout) {
+          const float bco = bias_s[co - cout0], sl = slope_s[co - cout0];
+          float v[4] = {acc[m][0][r] + bco, acc[m][1][r] + bco, acc[m][2][r] + bco, acc[m][3][r] + bco};
+          if (SQ) {
+            // 1x1, stride 1: input and output share their geometry
+            const float xs[4] = {cur[e].x.x, cur[e].x.y, cur[e].x.z, cur[e].x.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              if (v0[j] < 0) v0[j] = v0[j] * s0;
-              if (v1[j] < 0) v1[j] = v1[j] * s1;
+              const float nrm = sqrtf(v[j]);
+              v[j] = act == 2 ? xs[j] / nrm : xs[j] * nrm;
             }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (v[j] < 0) v[j] = v[j] * sl;
+          }
+          if (RES) {
+            v[0] = cur[e].r.x + v[0];
+            v[1] = cur[e].r.y + v[1];
+            v[2] = cur[e].r.z + v[2];
+            v[3] = cur[e].r.w + v[3];
           }
 #pragma unroll
           for (int j = 0; j < 4; j++)
-            if (col + j >= trim_at) v0[j] = v1[j] = 0.f;
-          float *q = outp + (size_t)(co >> 2) * vout.cs + (size_t)(2 * orow + ((co >> 1) & 1)) * vout.rs + 2 * col;
-          *reinterpret_cast<float4 *>(q) = make_float4(v0[0], v1[0], v0[1], v1[1]);
-          *reinterpret_cast<float4 *>(q + 4) = make_float4(v0[2], v1[2], v0[3], v1[3]);
-          continue;
+            if (col + j >= trim_at) v[j] = 0.f;
+          *reinterpret_cast<float4 *>(outp + (size_t)co * vout.cs + (size_t)orow * vout.rs + col) =
+              make_float4(v[0], v[1], v[2], v[3]);
         }
-        const float bco = ep.bias ? ep.bias[co] : 0.f;
-        const float sl = (act == 1) ? ep.slope[co] : 0.f;
-        float v[4] = {acc[m][0][r] + bco, acc[m][1][r] + bco, acc[m][2][r] + bco, acc[m][3][r] + bco};
-        if (act == 1) {
+      }
+      if ((RES || SQ) && bi + 1 < NB) {
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (v[j] < 0) v[j] = v[j] * sl;
-        } else if (act == 2 || act == 3) {
-          // 1x1, stride 1: input and output share their geometry
-          const float4 xv = *reinterpret_cast<const float4 *>(inp + (size_t)co * vin.cs + (size_t)orow * vin.rs + col);
-          const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const float nrm = sqrtf(v[j]);
-            v[j] = act == 2 ? xs[j] / nrm : xs[j] * nrm;
-          }
-        } else if (act == 4) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = 1.f / (1.f + expf(-v[j]));
-        }
-        if (gatep) {
-          const float4 gv = *reinterpret_cast<const float4 *>(gatep + (size_t)co * ep.vgate.cs + (size_t)orow * ep.vgate.rs + col);
-          v[0] = gv.x * v[0];
-          v[1] = gv.y * v[1];
-          v[2] = gv.z * v[2];
-          v[3] = gv.w * v[3];
-        }
-        if (resp) {
-          const float4 rv = *reinterpret_cast<const float4 *>(resp + (size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + col);
-          v[0] = rv.x + v[0];
-          v[1] = rv.y + v[1];
-          v[2] = rv.z + v[2];
-          v[3] = rv.w + v[3];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (col + j >= trim_at) v[j] = 0.f;
-        *reinterpret_cast<float4 *>(outp + (size_t)co * vout.cs + (size_t)orow * vout.rs + col) =
-            make_float4(v[0], v[1], v[2], v[3]);
+        for (int e = 0; e < EB; e++) cur[e] = nxt[e];
       }
     }
   }
 }
 
-template <int WM, bool SQ>
+template <int WM, bool SQ, bool RES>
 int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout,
                    int cout_pad, const ConvView &vin, const ConvView &vout, const ConvEpilogue &ep,
                    hipStream_t stream) {
@@ -813,8 +818,8 @@ int launch_conv1x1(const float *in, const float *wp, float *out, int tn, int cin
     pconv_set_error("conv2d: grid %lld out of range", grid);
     return PCONV_EINVAL;
   }
-  const size_t smem = (size_t)kpad * BM * sizeof(float);
-  auto kern = conv1x1_rb_kernel<WM, SQ>;
+  const size_t smem = ((size_t)kpad * BM + 2 * BM) * sizeof(float);  // slab + bias / slope table
+  auto kern = conv1x1_rb_kernel<WM, SQ, RES>;
   if (smem > 64 * 1024) {
     static std::atomic<unsigned long long> raised{0};
     int device = 0;
@@ -848,7 +853,7 @@ inline bool use_resident_1x1(int cin, int cout, int tn, int h, int w) {
   if (env && env[0] == 't') return false;
   const int kpad = (cin + 15) / 16 * 16;
   const int bm = cout > 96 ? 192 : 96;
-  if (!(cin >= 32 && cin % 16 == 0 && cout > 32 && (size_t)kpad * bm * sizeof(float) <= 150 * 1024)) return false;
+  if (!(cin >= 32 && cin % 16 == 0 && cout > 32 && ((size_t)kpad * bm + 2 * bm) * sizeof(float) <= 160 * 1024)) return false;
   if (w < 4) return false;
   if (env && env[0] == 'r') return true;  // forced (tests, A/B measurements)
   // Measured (MI355X, layers of a 4096x2048 frame).  Against the tiled kernel of round 2's first
@@ -1004,11 +1009,15 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
     BY_TILE(3, 1, 4)
   } else if (k == 3 && stride == 2) {
     BY_TILE(3, 2, 4)
-  } else if (k == 1 && stride == 1 && use_resident_1x1(cin, cout, tn, h, w)) {
-    if (cout > 96)
-      rc = launch_conv1x1<2, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+  } else if (k == 1 && stride == 1 && !gate && !d2w && act != 4 && use_resident_1x1(cin, cout, tn, h, w)) {
+    if (cout > 96 && residual)
+      rc = launch_conv1x1<2, false, true>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+    else if (cout > 96)
+      rc = launch_conv1x1<2, false, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+    else if (residual)
+      rc = launch_conv1x1<1, false, true>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
     else
-      rc = launch_conv1x1<1, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+      rc = launch_conv1x1<1, false, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
   } else if (k == 1 && stride == 1) {
     BY_TILE(1, 1, PCONV_KC1)
   } else {
@@ -1042,10 +1051,14 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
   PCONV_REQUIRE(view_ok(vin, ch, h, w) && view_ok(vout, ch, h, w) && (!residual || view_ok(ep.vres, ch, h, w)),
                 "gdn: strides overlap");
   int rc;
-  if (use_resident_1x1(ch, ch, tn, h, w) && ch > 96)
-    rc = launch_conv1x1<2, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  if (use_resident_1x1(ch, ch, tn, h, w) && ch > 96 && residual)
+    rc = launch_conv1x1<2, true, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  else if (use_resident_1x1(ch, ch, tn, h, w) && ch > 96)
+    rc = launch_conv1x1<2, true, false>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  else if (use_resident_1x1(ch, ch, tn, h, w) && residual)
+    rc = launch_conv1x1<1, true, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
   else if (use_resident_1x1(ch, ch, tn, h, w))
-    rc = launch_conv1x1<1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+    rc = launch_conv1x1<1, true, false>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
   else if (ch > 96)
     rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)
