@@ -394,6 +394,15 @@ __device__ __forceinline__ void conv_chunk_prologue(float (&a)[kAhead + 1][C::MT
 #define PCONV_1X1_EPI_ROWS 16
 #endif
 
+#ifdef PCONV_CONV_STAMP
+// profiling build: s_memtime of one workgroup per launch: [wave][entry, first chunk, end of the matrix loop, end,
+// s_memrealtime at entry (100 MHz), SIMD/CU id]
+__device__ unsigned long long conv_stamps[64][8][6];
+#define CONV_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define CONV_STAMP(v)
+#endif
+
 template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
 __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_WAVES_EU : 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
@@ -406,6 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
   constexpr int kThreads = C::THREADS;
   constexpr int kTileRows = C::ROWS;
   extern __shared__ float lds[];
+  CONV_STAMP(st0);
 
   // block -> (cout block, row tile, column tile, tile-batch index).  Row tiles run
   // fastest on purpose: workgroups are dealt to the 8 XCDs x 4 shader engines by
@@ -523,6 +533,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
 
   stager(0, 0).issue_all();
   __syncthreads();  // (also waits for the DMA: vmcnt(0))
+  CONV_STAMP(st1);
 
   for (int chunk = 0; chunk < nchunk; chunk++) {
     // the other buffer's last readers finished before the barrier that ended the
@@ -543,6 +554,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
 #endif
   }
 
+  CONV_STAMP(st2);
   // (the barrier that ended the last chunk: nobody reads the stage memory any more)
   static_assert(2 * C::BM <= C::STAGE && C::BM <= kThreads, "bias / slope table fits the stage memory");
   if (tid < C::BM) {
@@ -555,6 +567,20 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
 #endif
   conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,
                                                                                       cout, ho, wo, wm, wn, l31, half, lds, lds + C::BM);
+#ifdef PCONV_CONV_STAMP
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left)
+    CONV_STAMP(st3);
+    // sixty-four consecutive workgroups from the middle of the grid: who runs when, on which CU
+    const int slot = (int)blockIdx.x - (int)(gridDim.x / 2);
+    if (slot >= 0 && slot < 64 && lane == 0) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned long long *o = conv_stamps[slot][wave & 7];
+      o[0] = st0, o[1] = st1, o[2] = st2, o[3] = st3, o[4] = hw, o[5] = blockIdx.x;
+    }
+  }
+#endif
 }
 
 // ---- weight-resident, register-blocked 1x1 convolution ---------------------------------
@@ -865,6 +891,12 @@ inline bool use_resident_1x1(int cin, int cout, int tn, int h, int w) {
   (void)tn, (void)h;
   return false;
 }
+
+#ifdef PCONV_CONV_STAMP
+extern "C" int pconv_conv_read_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_stamps), sizeof(conv_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ packed, int cout,
