@@ -238,6 +238,84 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvE
   }
 }
 
+// The way out of the 1x1 / GDN layers without gate, sigmoid or depth-to-width store, as straight-line code: what a
+// row reads from memory (RES: the residual, SQ: the GDN's own input) is requested a batch of EB rows ahead, with
+// addresses clamped into the tensors instead of guards around the loads, so that the compiler counts loads and
+// stores (vmcnt(n)) and a batch's wait leaves the next batch and the stores of the one before in flight.  In
+// conv_epilogue a 1x1 workgroup spends 62 % of its life in "request 16 rows, wait for all of them, store 16 rows",
+// three times (profiles/round3_1x1_timeline.txt).  Same operations per output, in the same order: identical bits.
+template <int MT, int NT, int WN, bool SQ, bool RES>
+__device__ __forceinline__ void conv_epilogue_pipe(f32x16 (&acc)[MT][NT], const ConvEpilogue &ep, const float *inp,
+                                                   float *outp, const ConvView &vin, const ConvView &vout, int t, int r0,
+                                                   int c0, int cout0, int cout, int ho, int wo, int wm, int wn, int l31,
+                                                   int half, const float *bias_s, const float *slope_s) {
+  const int act = ep.act;
+  const int trim_at = ((ep.trim || act == 2 || act == 3) && ep.col_limit) ? ep.col_limit[t % ep.npart] : wo;
+  const float *resp = RES ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
+  constexpr int NROW = MT * 16, EB = PCONV_PIPE_ROWS(SQ && RES), NB = NROW / EB;
+  struct RowIn {
+    float r[NT], x[NT];
+  };
+  auto row_cout = [&](int q) { return cout0 + (wm * MT + (q >> 4)) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * half; };
+  auto request = [&](int q) {
+    RowIn v;
+    int co = row_cout(q);
+    co = co < cout ? co : cout - 1;
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+      const int seg = wn * NT + n;
+      int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+      orow = orow < ho ? orow : ho - 1;
+      ocol = ocol < wo ? ocol : wo - 1;
+      v.r[n] = RES ? resp[(size_t)co * ep.vres.cs + (size_t)orow * ep.vres.rs + ocol] : 0.f;
+      v.x[n] = SQ ? inp[(size_t)co * vin.cs + (size_t)orow * vin.rs + ocol] : 0.f;  // 1x1, stride 1: same geometry
+    }
+    return v;
+  };
+  RowIn cur[EB], nxt[EB];
+  if (RES || SQ) {
+#pragma unroll
+    for (int e = 0; e < EB; e++) cur[e] = request(e);
+  }
+#pragma unroll
+  for (int bi = 0; bi < NB; bi++) {
+    if ((RES || SQ) && bi + 1 < NB) {
+#pragma unroll
+      for (int e = 0; e < EB; e++) nxt[e] = request((bi + 1) * EB + e);
+    }
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+      const int q = bi * EB + e, m = q >> 4, r = q & 15;
+      const int co = row_cout(q);
+      if (co < cout) {
+        const float bco = bias_s[co - cout0], sl = slope_s[co - cout0];
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int seg = wn * NT + n;
+          const int orow = r0 + (seg >> 1), ocol = c0 + (seg & 1) * 32 + l31;
+          if (orow < ho && ocol < wo) {
+            float v = acc[m][n][r] + bco;
+            if (SQ) {
+              const float xv = cur[e].x[n];
+              const float nrm = sqrtf(v);
+              v = act == 2 ? xv / nrm : xv * nrm;
+            } else if (act == 1) {
+              if (v < 0) v = v * sl;
+            }
+            if (RES) v = cur[e].r[n] + v;
+            if (ocol >= trim_at) v = 0.f;
+            outp[(size_t)co * vout.cs + (size_t)orow * vout.rs + ocol] = v;
+          }
+        }
+      }
+    }
+    if ((RES || SQ) && bi + 1 < NB) {
+#pragma unroll
+      for (int e = 0; e < EB; e++) cur[e] = nxt[e];
+    }
+  }
+}
+
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void glb_ptr_t;
 typedef const __attribute__((address_space(1))) char glb_bytes_t;
@@ -390,6 +468,10 @@ __device__ __forceinline__ void conv_chunk_prologue(float (&a)[kAhead + 1][C::MT
 #ifndef PCONV_1X1_WAVES_EU
 #define PCONV_1X1_WAVES_EU 2
 #endif
+// rows a batch of the pipelined way out requests ahead (both: the layer reads two tensors)
+#ifndef PCONV_PIPE_ROWS
+#define PCONV_PIPE_ROWS(both) ((both) ? 8 : 8)
+#endif
 #ifndef PCONV_1X1_EPI_ROWS
 #define PCONV_1X1_EPI_ROWS 16
 #endif
@@ -403,7 +485,8 @@ __device__ unsigned long long conv_stamps[64][8][6];
 #define CONV_STAMP(v)
 #endif
 
-template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ>
+// WAY: 0 = conv_epilogue (every epilogue, flags at run time), 1 / 2 = conv_epilogue_pipe without / with residual
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ, int WAY = 0>
 __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_WAVES_EU : 2) void conv_mfma_kernel(
     const float *__restrict__ in, const float *__restrict__ wp, float *__restrict__ out, int cin, int h,
     int w, int cout, int cout_pad, int ho, int wo, int tiles_r, int tiles_c, int cblocks, int xcd_group, ConvView vin,
@@ -565,8 +648,14 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
 #ifdef PCONV_ABL_NOEPI
   if (cin == -12345)
 #endif
-  conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,
-                                                                                      cout, ho, wo, wm, wn, l31, half, lds, lds + C::BM);
+  {
+    if constexpr (WAY == 0)
+      conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,
+                                                                                          cout, ho, wo, wm, wn, l31, half, lds, lds + C::BM);
+    else
+      conv_epilogue_pipe<MT, NT, WN, SQ, WAY == 2>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn,
+                                                  l31, half, lds, lds + C::BM);
+  }
 #ifdef PCONV_CONV_STAMP
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left)
@@ -898,6 +987,12 @@ extern "C" int pconv_conv_read_stamps(unsigned long long *out) {
 }
 #endif
 
+// PCONV_CONV1X1_WAYOUT=batch: the 1x1 / GDN layers keep conv_epilogue (A/B measurements)
+inline bool pipe_way_out() {
+  static const bool on = !(getenv("PCONV_CONV1X1_WAYOUT") && getenv("PCONV_CONV1X1_WAYOUT")[0] == 'b');
+  return on;
+}
+
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ packed, int cout,
                                    int red, int cout_pad, int red_pad) {
@@ -907,7 +1002,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
   packed[i] = (co < cout && kk < red) ? w[(size_t)co * red + kk] : 0.f;
 }
 
-template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ = false>
+template <int MT, int NT, int WM, int WN, int KS, int S, int KC, bool SQ = false, int WAY = 0>
 int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout,
                 int cout_pad, int ho, int wo, const ConvView &vin, const ConvView &vout, const ConvEpilogue &ep,
                 hipStream_t stream) {
@@ -923,7 +1018,7 @@ int launch_conv(const float *in, const float *wp, float *out, int tn, int cin, i
     return PCONV_EINVAL;
   }
   const size_t smem = (size_t)2 * C::STAGE * sizeof(float);
-  auto kern = conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ>;
+  auto kern = conv_mfma_kernel<MT, NT, WM, WN, KS, S, KC, SQ, WAY>;
   if (smem > 64 * 1024) {
     // the dynamic-LDS limit is a per-device attribute of the function: raise it once on
     // every device this process launches the instantiation on (one process may drive
@@ -1050,6 +1145,14 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
       rc = launch_conv1x1<1, false, true>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
     else
       rc = launch_conv1x1<1, false, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+  } else if (k == 1 && stride == 1 && !gate && !d2w && act != 4 && residual && pipe_way_out()) {
+    // (the pipelined way out, see conv_epilogue_pipe; PCONV_CONV1X1_WAYOUT=batch: the generic one)
+    if (cout > 96)
+      rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, false, 2>(ARGS);
+    else if (cout > 32)
+      rc = launch_conv<3, 1, 1, 8, 1, 1, PCONV_KC1, false, 2>(ARGS);
+    else
+      rc = launch_conv<1, 1, 1, 4, 1, 1, PCONV_KC1, false, 2>(ARGS);
   } else if (k == 1 && stride == 1) {
     BY_TILE(1, 1, PCONV_KC1)
   } else {
@@ -1091,6 +1194,10 @@ extern "C" int pconv_gdn(const float *in, const float *packed_gamma, const float
     rc = launch_conv1x1<1, true, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
   else if (use_resident_1x1(ch, ch, tn, h, w))
     rc = launch_conv1x1<1, true, false>(in, packed_gamma, out, tn, ch, h, w, ch, cp, vin, vout, ep, s);
+  else if (pipe_way_out() && ch > 96 && residual)
+    rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, true, 2>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
+  else if (pipe_way_out() && ch > 96)
+    rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, true, 1>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 96)
     rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, true>(in, packed_gamma, out, tn, ch, h, w, ch, cp, h, w, vin, vout, ep, s);
   else if (ch > 32)
