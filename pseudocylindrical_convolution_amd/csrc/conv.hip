@@ -989,8 +989,8 @@ extern "C" int pconv_conv_read_stamps(unsigned long long *out) {
 
 // PCONV_CONV1X1_WAYOUT=batch: the 1x1 / GDN layers keep conv_epilogue (A/B measurements)
 inline bool pipe_way_out() {
-  static const bool on = !(getenv("PCONV_CONV1X1_WAYOUT") && getenv("PCONV_CONV1X1_WAYOUT")[0] == 'b');
-  return on;
+  const char *env = getenv("PCONV_CONV1X1_WAYOUT");  // (read per call: the parity test switches it)
+  return !(env && env[0] == 'b');
 }
 
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded

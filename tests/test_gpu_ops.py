@@ -453,6 +453,13 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
 
     monkeypatch.setenv("PCONV_CONV1X1", "tiled")
     tiled = variants()
+    # the tiled kernel's two ways out -- rows requested a batch ahead as straight-line code (default, for
+    # layers with a residual and the GDN pair) and conv_epilogue's whole-tile batches: identical bits
+    monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "batch")
+    batched = variants()
+    monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
+    for i, (a, r) in enumerate(zip(tiled, batched)):
+        assert torch.equal(a, r), "way out, variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
     monkeypatch.setenv("PCONV_CONV1X1", "resident")
     resident = variants()
     monkeypatch.delenv("PCONV_CONV1X1")
