@@ -33,6 +33,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTileCols = 64;
+// rows a batch of the pipelined way out requests ahead (both: the layer reads two tensors)
+#ifndef PCONV_PIPE_ROWS
+#define PCONV_PIPE_ROWS(both) ((both) ? 8 : 8)
+#endif
 #ifndef PCONV_KC1
 #define PCONV_KC1 16  // input channels per LDS stage of the 1x1 layers
 #endif
@@ -467,10 +471,6 @@ __device__ __forceinline__ void conv_chunk_prologue(float (&a)[kAhead + 1][C::MT
 // epilogue batch (tuning knobs; the 3x3 kernels keep 4 waves per SIMD = two 8-wave workgroups per CU)
 #ifndef PCONV_1X1_WAVES_EU
 #define PCONV_1X1_WAVES_EU 2
-#endif
-// rows a batch of the pipelined way out requests ahead (both: the layer reads two tensors)
-#ifndef PCONV_PIPE_ROWS
-#define PCONV_PIPE_ROWS(both) ((both) ? 8 : 8)
 #endif
 #ifndef PCONV_1X1_EPI_ROWS
 #define PCONV_1X1_EPI_ROWS 16

@@ -540,6 +540,14 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
                 p.tw + pad_out) * cout;
   }
   stage_weights<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x);
+  // bias and slope of the set's outputs in LDS, once: loaded per group in front of their use they sat behind the
+  // store of the group before (vmcnt counts stores too, and a guarded load is waited for with vmcnt(0)): one
+  // exposed store -> load round trip per group and wave
+  __shared__ float bs_tab[2][GO * CIN];  // (cout = 3 ngroup, ngroup = CIN or CIN / 3)
+  for (int i = threadIdx.x; i < cout; i += BLOCK) {
+    bs_tab[0][i] = bias[set * cout + i];
+    bs_tab[1][i] = slope ? slope[set * cout + i] : 1.f;  // (v * 1 is v)
+  }
   __syncthreads();
   for (int tc = 0; tc < g.ngroup; tc++) {
     // the next group's slab goes to the other buffer while this one is used (its
@@ -603,10 +611,9 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
       const int o = quad == 0 ? 0 : (quad == 2 ? 1 : 2);
       if ((lane & 3) == 0 && quad != 3 && idx0 + j < g.npos) {
         const int pout = tc * GO + o;
-        const int bidx = set * cout + pout;
         const size_t ob = j == 0 ? obase[0] : (j == 1 ? obase[1] : (j == 2 ? obase[2] : obase[3]));
-        float v = tot + bias[bidx];
-        if (slope && v < 0) v = v * slope[bidx];
+        float v = tot + bs_tab[0][pout];
+        if (v < 0) v = v * bs_tab[1][pout];
         if (residual) v = v + residual[ob + pout];
         y[ob + pout] = v;
       }
