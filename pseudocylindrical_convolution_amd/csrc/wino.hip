@@ -525,7 +525,14 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #ifdef PCONV_WINO_ABL_NOPDMA
     auto pd = [&](auto) {};
 #else
-    auto pd = [&](auto j_c) { patch_piece(chunk + 2, vb, decltype(j_c)::value); };
+    // (the last piece holds elements 1536 .. 1583 of the stage: wave 0's lanes 0-47; the other waves would only
+    // re-read element 0 into the slack.  The counted wait at the barrier counts the YOUNGEST instructions, the
+    // weight pieces, so the waves need not issue the same number of older ones.)
+    auto pd = [&](auto j_c) {
+      constexpr int J = decltype(j_c)::value;
+      if (J * kThreads + 64 >= PSZ && wave != 0) return;
+      patch_piece(chunk + 2, vb, J);
+    };
 #endif
 #ifdef PCONV_WINO_ABL_NOWDMA
     auto wd = [&](auto) {};
