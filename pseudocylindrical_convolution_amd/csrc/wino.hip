@@ -21,18 +21,24 @@
 // and a wave still has ~60 registers for operands in flight (two waves per SIMD, 256 registers each;
 // the first version, sixteen waves of one GEMM and 128 registers, had none: 207 vs 214-224 TFLOP/s).
 //   * input patch (4 channels x 6 x 66) -> LDS by LDS-DMA, double buffered;
-//   * input transform LDS -> LDS into a double-buffered V[xi][ci][tile] by waves 0-3 (one per SIMD; all
-//     sixteen values of a (channel, tile) pair per thread) before their matrix block, while their SIMD
-//     partners, waves 4-7, are on the matrix pipe;
+//   * input transform LDS -> LDS into a double-buffered V[xi][ci][tile]: every wave does half of one
+//     (channel, tile) pair per thread (waves 0-3 rows 0-1 of Bt d, waves 4-7 rows 2-3), in pieces placed
+//     BETWEEN its own MFMAs (wino_mma_steps): next to a wave that streams fp32 MFMAs its SIMD partner gets
+//     about one vector / LDS instruction per matrix instruction issued, so a transform in front of the
+//     matrix block made the two waves of a SIMD take turns (in-kernel stamps: 4 100 cycles per chunk for
+//     3 072 cycles of MFMAs; 3 670 now);
 //   * transformed weights U[xi]: nobody but the wave that owns xi reads them, so each wave streams its own
-//     slice through a PRIVATE four-stage LDS ring by 16-byte LDS-DMA and waits with s_waitcnt only;
+//     slice through a PRIVATE four-stage LDS ring by 16-byte LDS-DMA and waits with s_waitcnt only; the DMA
+//     instructions of a chunk also sit between MFMAs, addressed as scalar base + 32-bit lane offset;
 //   * one workgroup barrier per 4 input channels (24 MFMAs per wave), main loop unrolled over four chunks
 //     (ring slots are compile-time constants);
 //   * output transform: the sixteen M[xi] of an output meet in LDS (one 32-cout x 32-tile block of all
 //     xi per round, 64 KB, two buffers), each thread turns (cout, tile) pairs into 2 x 2 outputs and applies
 //     the epilogue of the layer (bias, PReLU, residual, trim, or the Dtow pixel shuffle), stored as float2 /
-//     float4 runs.  (Measured alternative: three rounds with 16-byte writes / 8-byte reads -- half the LDS
-//     instructions -- is not faster: 5.04 vs 5.02 ms.)
+//     float4 runs; no load of the way out sits behind a branch or a store (bias / slope in an LDS table,
+//     residual requested two rounds ahead with counted waits: the kind of layer is a template parameter).
+//     (Measured alternative: three rounds with 16-byte writes / 8-byte reads -- half the LDS instructions
+//     -- is not faster: 5.04 vs 5.02 ms.)
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
