@@ -160,6 +160,12 @@ __device__ __forceinline__ void wino_wait(float (&a)[3], float (&b)[2]) {
 template <int U, int VB, int ST>
 __device__ __forceinline__ void wino_read_step(float (&a)[3], float (&b)[2], unsigned abase, unsigned bbase) {
   constexpr int x = ST >> 1, kp = ST & 1;
+#ifdef PCONV_WINO_ABL_NOLDSREAD
+  if constexpr (ST != 0) {  // timing ablation: only the first step of a chunk reads its operands
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]));
+    return;
+  }
+#endif
   constexpr int aoff = (U * USZ + (kp * 2 * XW + x) * CO) * 4;
   constexpr int boff = (VB * VSZ + (x * KC + kp * 2) * (TX * TY)) * 4;
   a[0] = wino_lds_read<aoff>(abase);
