@@ -275,9 +275,13 @@ int pconv_conv2d(const float *in, const float *packed_w, const float *bias, floa
  * algorithm cuDNN runs the reference's fp32 3x3 nn.Conv2d layers with (model_zoo_v2.py:41-45,83-86,
  * 158-164).  Results differ from pconv_conv2d's fmaf chain by rounding (~1e-6 relative).
  * packed_u from pconv_wino_pack_weight (pconv_wino_packed_size floats).  Arguments as pconv_conv2d
- * without k / stride / gate; act 0 or 1; views: 9 strides (in, out, residual) or NULL.  Takes layers
- * with pconv_wino_supported(...) != 0 (even output size, cin >= 8, cout >= 32); rows of out /
- * residual must start on 8-byte boundaries. */
+ * without k / stride / gate; act 0 or 1; views: 9 strides (in, out, residual) or NULL.  Takes the
+ * layers pconv_wino_supported(...) accepts -- the single source of truth: cin % 16 == 0 (no ragged
+ * channel path), cout >= 32, h, w >= 4, even output size, cout % 4 == 0 with d2w -- and returns
+ * PCONV_EINVAL for anything else; rows of out / residual must start on 8-byte boundaries.  Input
+ * views whose KC-channel chunk spans 4 GiB or more are refused (the LDS-DMA addresses a chunk as a
+ * 64-bit uniform base + a 32-bit byte offset per lane); pconv_conv2d does the same for its 16-channel
+ * chunks. */
 long long pconv_wino_packed_size(int cout, int cin);
 int pconv_wino_pack_weight(const float *w, float *packed, int cout, int cin, void *stream);
 int pconv_wino_supported(int cin, int h, int w, int cout, int d2w);

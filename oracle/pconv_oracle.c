@@ -948,6 +948,39 @@ void orc_entropy_conv(const float *input, const float *weight, const float *bias
         part[tid] = s;
       }
       sum = reduce_ref128(part);
+    } else if (order == 2) {
+      /* The product's order since round 4 ("causal-compact"): only the entries the causal mask lets
+       * through are enumerated -- by window anti-diagonal d = kh + kw, then kh, then input channel:
+       *     e = 0;  for d in 0..2(k-1):  U = clamp(T - d, 0, ngroup) * group_in,  T = tc + (k-1) + slack
+       *               for kh in max(0, d-(k-1)) .. min(k-1, d):  for ci in 0..U-1:  entry e++ = (kh, d-kh, ci)
+       * lane e % 64 accumulates its entries in ascending e with fmaf, then the xor butterfly 32..1.
+       * (A masked entry multiplies a weight the reference's conv_mask_v5 / v6 zeroes: leaving it out
+       * adds nothing, and every group's usable set is a PREFIX-free compact list, so a kernel does
+       * ceil(L/64) rounds instead of ceil(25 cin / 64): half of them on average.) */
+      const float *wrow = weight + ((i64)nbatch * nout + pout) * red;
+      const int wpad = width + 2 * pad_in;
+      const float *base = input + (i64)qn * channel * index_stride + (i64)(th - half_kernel + pad_in) * wpad +
+                          (tw - half_kernel + pad_in);
+      const int ngrp = channel / group_in;
+      const int T = tc + (kernel_size - 1) + (constrain == 5 ? 0 : 1);
+      int e = 0;
+      for (int lane = 0; lane < 64; lane++) part[lane] = 0;
+      for (int d = 0; d <= 2 * (kernel_size - 1); d++) {
+        int ug = T - d;
+        if (ug > ngrp) ug = ngrp;
+        if (ug <= 0) continue;
+        const int U = ug * group_in;
+        const int kh0 = d - (kernel_size - 1) > 0 ? d - (kernel_size - 1) : 0;
+        const int kh1 = d < kernel_size - 1 ? d : kernel_size - 1;
+        for (int kh = kh0; kh <= kh1; kh++) {
+          const int kw = d - kh;
+          const float *src = base + (i64)kh * wpad + kw;
+          const float *wt = wrow + kh * kernel_size + kw;
+          for (int ci = 0; ci < U; ci++, e++)
+            part[e & 63] = fmaf(src[(i64)ci * index_stride], wt[ci * skernel], part[e & 63]);
+        }
+      }
+      sum = reduce_xor64(part);
     } else {
       /* same arithmetic as the plain statement of this order (lane l of 64 walks
        * kk = l, l+64, ... with kk = tap*channel + ci, skipping ci >= the tap's causal

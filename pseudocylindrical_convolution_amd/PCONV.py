@@ -1118,6 +1118,10 @@ def _aligned8(t):
     return t.data_ptr() % 8 == 0 and t.stride(0) % 2 == 0 and t.stride(1) % 2 == 0 and t.stride(2) % 2 == 0
 
 
+# 3x3 stride-1 calls that took the direct kernel although Winograd was selected, by (cin, h, w, cout, d2w)
+# (on the codec path: the 3-channel input and 12-channel output layers only)
+conv_fallbacks = {}
+
 # when set to an object with a `records` list, every tile-conv / GDN launch is bracketed
 # by events on its own stream: (kernel instantiation, class label, algorithmic flops,
 # start, end).  Used by bench.py for the live roofline figures; None in normal operation.
@@ -1231,9 +1235,14 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     residual = _like_output(residual, out, "tile_conv2d: residual")
     # 3x3 stride-1 layers: Winograd F(2x2, 3x3) on the matrix cores (csrc/wino.hip) unless
     # PCONV_CONV3X3=direct asks for the fmaf-chain kernel (the bit-exact form the oracle restates)
-    wino = (k == 3 and stride == 1 and not sigmoid and gate is None and conv3x3_mode() == "wino" and
-            _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1 and
+    want_wino = k == 3 and stride == 1 and not sigmoid and gate is None and conv3x3_mode() == "wino"
+    wino = (want_wino and _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1 and
             _aligned8(out) and (residual is None or _aligned8(residual)))
+    if want_wino and not wino:
+        # a plain 3x3 stride-1 layer that Winograd was selected for went to the direct kernel (shape not
+        # taken, or output / residual rows not 8-byte aligned): counted, so that the choice is never silent
+        key = (cin, h, w, cout, bool(d2w))
+        conv_fallbacks[key] = conv_fallbacks.get(key, 0) + 1
     probe = conv_probe
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -343,9 +343,6 @@ struct ConvStager {
   __device__ __forceinline__ void issue() const {
     if (!active) return;
     if constexpr (J < C::XLD) {
-#ifdef PCONV_ABL_NOXDMA
-      return;
-#endif
       const int e = tid + J * C::THREADS;
       if (e < C::XSZ) {
         unsigned off = xoffs[J];  // bytes
@@ -362,9 +359,6 @@ struct ConvStager {
                                          (lds_ptr_t *)(xs + J * C::THREADS + wave * 64), 4, 0, 0);
       }
     } else {
-#ifdef PCONV_ABL_NOWDMA
-      return;
-#endif
       constexpr int JW = J - C::XLD;
       const int e4 = tid + JW * C::THREADS;
       if (e4 < C::WSZ / 4) {
@@ -632,9 +626,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int d = 0; d < C::ND; d++) bbase[n][d] += flip;
-#ifndef PCONV_ABL_NOBAR
     __syncthreads();
-#endif
   }
 
   CONV_STAMP(st2);
@@ -645,9 +637,6 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
     lds[C::BM + tid] = my_slope;
   }
   __syncthreads();
-#ifdef PCONV_ABL_NOEPI
-  if (cin == -12345)
-#endif
   {
     if constexpr (WAY == 0)
       conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,

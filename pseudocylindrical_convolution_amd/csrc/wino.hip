@@ -12,7 +12,12 @@
 // i.e. 2.25 x fewer matrix-core operations for the same convolution -- what cuDNN picks for the
 // reference's fp32 3x3 layers too.  Results differ from the k-ascending fmaf chain of conv.hip by
 // rounding only (~1e-6 relative; the north-star bound is 1e-4); conv.hip stays the bit-exact form
-// (PCONV_CONV3X3=direct) and takes everything this kernel does not (stride 2, gates, odd sizes).
+// (PCONV_CONV3X3=direct) and takes everything this kernel does not: stride 2, gates, odd sizes, and any
+// cin that is not a multiple of 16 or cout < 32 (pconv_wino_supported is the single source of truth).
+//
+// LDS contract: the kernel's dynamic LDS must start at LDS byte 0 (no static __shared__ in this
+// translation unit's kernel): wino_store_round splits the second exchange buffer's address between
+// M0[15:0] and the 16-bit immediate of ds_write_addtid assuming lds0 == 0; the kernel traps otherwise.
 //
 // Mapping.  A workgroup = 8 waves = 96 couts x 64 Winograd tiles (2 tile rows x 32 tile columns = 4 x 64
 // output pixels).  Wave w owns the GEMMs xi = 2w, 2w+1: two 96 x 64 accumulator blocks of 3 x 2 MFMA tiles
@@ -160,12 +165,6 @@ __device__ __forceinline__ void wino_wait(float (&a)[3], float (&b)[2]) {
 template <int U, int VB, int ST>
 __device__ __forceinline__ void wino_read_step(float (&a)[3], float (&b)[2], unsigned abase, unsigned bbase) {
   constexpr int x = ST >> 1, kp = ST & 1;
-#ifdef PCONV_WINO_ABL_NOLDSREAD
-  if constexpr (ST != 0) {  // timing ablation: only the first step of a chunk reads its operands
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]));
-    return;
-  }
-#endif
   constexpr int aoff = (U * USZ + (kp * 2 * XW + x) * CO) * 4;
   constexpr int boff = (VB * VSZ + (x * KC + kp * 2) * (TX * TY)) * 4;
   a[0] = wino_lds_read<aoff>(abase);
@@ -238,13 +237,11 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
   __builtin_amdgcn_sched_barrier(0);
   float o[4];
   acc[X][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][0], b[S][0], acc[X][0][0], 0, 0, 0);
-#ifndef PCONV_WINO_ABL_NOTRANSFORM
   if constexpr (ST == 0) {
     __builtin_amdgcn_sched_barrier(0);
     wino_half_load<VB ^ 1>(h, rows);
     __builtin_amdgcn_sched_barrier(0);
   }
-#endif
   auto dma = [&](auto j_c) {  // DMA piece j of this step, if it has one
     constexpr int J = decltype(j_c)::value;
     if constexpr (IL && ST == 0 && J < PLD) {
@@ -263,24 +260,20 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
   acc[X][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][0], b[S][1], acc[X][0][1], 0, 0, 0);
   dma(integral_constant<int, 1>{});
   acc[X][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][1], b[S][0], acc[X][1][0], 0, 0, 0);
-#ifndef PCONV_WINO_ABL_NOTRANSFORM
   if constexpr (ST == 1 || ST == 2) {
     __builtin_amdgcn_sched_barrier(0);
     wino_half_math<ST - 1>(h, rows, o);
     __builtin_amdgcn_sched_barrier(0);
   }
-#endif
   dma(integral_constant<int, 2>{});
   acc[X][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][1], b[S][1], acc[X][1][1], 0, 0, 0);
   dma(integral_constant<int, 3>{});
   acc[X][2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][2], b[S][0], acc[X][2][0], 0, 0, 0);
-#ifndef PCONV_WINO_ABL_NOTRANSFORM
   if constexpr (ST == 1 || ST == 2) {
     __builtin_amdgcn_sched_barrier(0);
     wino_half_store<VB ^ 1, ST - 1>(h, o);
     __builtin_amdgcn_sched_barrier(0);
   }
-#endif
   acc[X][2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][2], b[S][1], acc[X][2][1], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (ST + 1 < NST) wino_mma_steps<U, VB, ST + 1, IL>(acc, a, b, abase, bbase, h, rows, pd, wd);
@@ -391,9 +384,6 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   };
   auto issue_patch = [&](int chunk, int buf, bool guard) {
     if (guard && chunk >= nchunk) return;
-#ifdef PCONV_WINO_ABL_NOPDMA
-    if (chunk >= PRING) return;
-#endif
 #pragma unroll
     for (int j = 0; j < PLD; j++) patch_piece(chunk, buf, j);
   };
@@ -414,9 +404,6 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   };
   auto issue_weights = [&](int chunk, bool guard) {
     if (guard && chunk >= nchunk) return;
-#ifdef PCONV_WINO_ABL_NOWDMA
-    if (chunk >= URING) return;
-#endif
     static_assert(ULD == 3, "weight pieces are issued by name");
     weight_piece(chunk, std::integral_constant<int, 0>{});
     weight_piece(chunk, std::integral_constant<int, 1>{});
@@ -492,6 +479,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   // per-lane LDS byte addresses of the operand fragments (see wino_read_step): A = weights
   // [stage][ci = 2 kp + half][x][96], B = V[vbuf][xi = 2 wave + x][ci = 2 kp + half][tile]
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);  // low half of the flat address = LDS offset
+  if (lds0 != 0) __builtin_trap();  // (uniform; see the LDS contract in the header comment)
   const unsigned abase = lds0 + (unsigned)((us_w - lds) + half * XW * CO + l31) * 4u;
   const unsigned bbase = lds0 + (unsigned)((Vs - lds) + ((wave * XW) * KC + half) * (TX * TY) + l31) * 4u;
 
@@ -511,19 +499,10 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     constexpr bool STEADY = decltype(steady_c)::value;
     constexpr int vb = U & 1;
     WINO_STAMP(t0);
-#ifdef PCONV_WINO_ABL_NOBAR
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-#ifdef PCONV_WINO_ABL_NOWDMA
-    if (STEADY)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
     if (STEADY)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ULD) : "memory");
-#endif
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     WINO_STAMP(t1);
     // steady state: the DMA instructions go inside the matrix block; head and tail chunks, where a stream may
     // have ended, keep them around it (a guard inside the block would be a join with 192 live accumulators)
@@ -534,9 +513,6 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     float a[2][3], bv[2][2];
     WinoRows rows;
     wino_read_step<U, vb, 0>(a[0], bv[0], abase, bbase);
-#ifdef PCONV_WINO_ABL_NOPDMA
-    auto pd = [&](auto) {};
-#else
     // (the last piece holds elements 1536 .. 1583 of the stage: wave 0's lanes 0-47; the other waves would only
     // re-read element 0 into the slack.  The counted wait at the barrier counts the YOUNGEST instructions, the
     // weight pieces, so the waves need not issue the same number of older ones.)
@@ -545,12 +521,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
       if (J * kThreads + 64 >= PSZ && wave != 0) return;
       patch_piece(chunk + 2, vb, J);
     };
-#endif
-#ifdef PCONV_WINO_ABL_NOWDMA
-    auto wd = [&](auto) {};
-#else
     auto wd = [&](auto j_c) { weight_piece(chunk + URING, j_c); };
-#endif
     wino_mma_steps<U, vb, 0, STEADY>(acc, a, bv, abase, bbase, half_t, rows, pd, wd);
     WINO_STAMP(t3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -587,19 +558,6 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   }
 #endif
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
-#ifdef PCONV_WINO_ABL_NOEPILOGUE
-  if (cin != -12345) {  // timing ablation: keep the accumulators alive, skip the way out
-    float keep = 0.f;
-#pragma unroll
-    for (int x = 0; x < XW; x++)
-#pragma unroll
-      for (int m = 0; m < 3; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) keep += acc[x][m][n][0];
-    if (keep == 123.456f) outp[0] = keep;
-    return;
-  }
-#endif
 
   // ---- output transform + epilogue ----
   // One 32-cout x 32-tile block of all sixteen M[xi] per round, through one of two exchange buffers

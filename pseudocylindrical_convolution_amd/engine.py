@@ -156,11 +156,21 @@ class CodecEngine(object):
     # 1/8 scale has 16 x fewer workgroups than at 1/2 scale; at 1/4 scale the last of its 6.5 rounds of
     # workgroups is half empty): blocks [0, ANALYSIS_SPLIT) of EncoderV2.net run frame by frame (their
     # activations are GBs at 4096x2048), the rest -- 1/4 scale and below -- on all frames of the call at
-    # once; likewise the first SYNTHESIS_SPLIT blocks of DecoderV2.net.  Every output is the same fmaf
-    # chain either way (bit-identical).  0 = whole transform frame by frame.  Measured (8 frames,
+    # once; likewise the first SYNTHESIS_SPLIT blocks of DecoderV2.net.  A tile's outputs do not depend
+    # on how many tiles a launch carries (same kernel, same per-tile arithmetic): bit-identical either
+    # way (tests/test_codec_cpu.py on the oracle, tests/test_gpu_bench_workload.py on the GPU at the
+    # metric size).  0 = whole transform frame by frame.  Measured (8 frames,
     # profiles/round3_split_transforms.txt): 0/0 52.6, 6/5 54.0, 3/8 54.5 MPix/s.
     ANALYSIS_SPLIT = int(os.environ.get("PCONV_ANALYSIS_SPLIT", "3"))
     SYNTHESIS_SPLIT = int(os.environ.get("PCONV_SYNTHESIS_SPLIT", "8"))
+
+    @staticmethod
+    def _split(knob, net, tail):
+        """the knob clamped to a split point that leaves the fused tail of the transform (the final
+        conv + sigmoid of EncoderV2: 1 module; the final conv + depth-to-width of DecoderV2: 2) on the
+        batched / per-frame side it belongs to; out-of-range values mean 'no split'"""
+        k = int(knob)
+        return k if 0 < k <= len(net) - tail else 0
 
     @staticmethod
     def _frame_of(x, i, tiles):
@@ -190,8 +200,9 @@ class CodecEngine(object):
     @torch.no_grad()
     def symbols(self, frames):
         """(n, 3, H, W) -> quantiser indices (n*16, valid_dim/4, 2h, 2w), dead columns zero."""
-        enc, n, k = self.enc, frames.shape[0], self.ANALYSIS_SPLIT
-        if n == 1 or k <= 0 or not hasattr(enc.encoder, "forward_range"):
+        enc, n = self.enc, frames.shape[0]
+        k = self._split(self.ANALYSIS_SPLIT, enc.encoder.net, 1) if hasattr(enc.encoder, "forward_range") else 0
+        if n == 1 or k <= 0:
             per_frame = [enc.ent.fill(enc.symbols(frames[i:i + 1])).clone() for i in range(n)]
             return per_frame[0] if len(per_frame) == 1 else torch.cat(per_frame, 0)
         mid = None
@@ -209,8 +220,9 @@ class CodecEngine(object):
     @torch.no_grad()
     def reconstruct(self, sym, n):
         """decoded symbols of n frames (n*16, valid_dim/4, 2h, 2w) -> (n, 3, H, W)"""
-        dec, tiles, k = self.dec, self.dec.npart, self.SYNTHESIS_SPLIT
-        if n == 1 or k <= 0 or not hasattr(dec.decoder, "forward_range"):
+        dec, tiles = self.dec, self.dec.npart
+        k = self._split(self.SYNTHESIS_SPLIT, dec.decoder.net, 2) if hasattr(dec.decoder, "forward_range") else 0
+        if n == 1 or k <= 0:
             out = [dec.reconstruct(sym[i * tiles:(i + 1) * tiles]).clone() for i in range(n)]
             return out[0] if n == 1 else torch.cat(out, 0)
         code_ext = dec.quant(dec.wtd(sym))
@@ -239,7 +251,8 @@ class CodecEngine(object):
         tiles = self.enc.ent.npart
         # with the split transform the symbols of ALL frames come out of one batched tail: the chunks
         # then only pipeline the entropy stage (GPU tables of chunk k+1 beside the CPU coding of chunk k)
-        batched = self.ANALYSIS_SPLIT > 0 and n > 1 and hasattr(self.enc.encoder, "forward_range")
+        batched = n > 1 and hasattr(self.enc.encoder, "forward_range") and \
+            self._split(self.ANALYSIS_SPLIT, self.enc.encoder.net, 1) > 0
         sym_all = self.symbols(frames).contiguous() if batched else None
         pending, out = [], []
         try:

@@ -245,7 +245,7 @@ class EncoderV2(nn.Module):
         last = len(self.net) - 1
         for m in self.net[lo:min(hi, last)]:
             x = m(x)
-        if hi > last:
+        if lo <= last < hi:  # (a range that starts behind the final conv is empty: it must not run twice)
             x = self.net[-1](x, (self.ctx, x.shape[3]), sigmoid=True, trim=self.trim)  # self.act fused
         return x
 
@@ -315,7 +315,7 @@ class DecoderV2(nn.Module):
         body = len(mods) - 2
         for m in mods[lo:min(hi, body)]:  # the blocks and the last pad
             x = m(x)
-        if hi > body:
+        if lo <= body < hi:
             # 3x3 conv to 12 channels + the depth-to-width that makes them 3 at full size
             x = mods[-2](x, (self.ctx, x.shape[3] - 2), d2w=mods[-1])
         return x

@@ -72,3 +72,37 @@ def test_ops_refuse_cpu_tensors():
     from pseudocylindrical_convolution_amd._native import PconvError
     with pytest.raises(PconvError, match="GPU tensor"):
         PCONV.DtowOp(2, True, 0, False).forward(torch.zeros(1, 4, 2, 2))
+
+
+def test_lds_dma_offsets_beyond_32_bits_are_refused():
+    """The LDS-DMA paths of both convolution kernels address a chunk of input channels as a 64-bit
+    uniform base + a 32-bit byte offset per lane (csrc/conv.hip, csrc/wino.hip).  A view whose chunk
+    spans 4 GiB or more must be refused on the host, before any launch (this is the regime of
+    pseudo_pad.cu:106's int32 count: SURVEY 7.3) -- a wrapped offset would read another tile's data."""
+    import ctypes
+    from pseudocylindrical_convolution_amd import _native
+    lib = _native.hip_lib()
+    dummy = 4096  # never dereferenced: the checks come first
+    cin, h, w, cout = 192, 6, 66, 192
+    ok_cs = h * w
+
+    def views(cs, n):
+        rows = [[cin * cs, cs, w], [cout * (h - 2) * (w - 2), (h - 2) * (w - 2), w - 2]] + [[0, 0, 0]] * (n - 2)
+        flat = [v for r in rows for v in r]
+        return (ctypes.c_longlong * len(flat))(*flat)
+
+    # Winograd: 4 channels per chunk -> 3 * cs * 4 bytes must stay below 2^32
+    big = (1 << 32) // 12 + 1
+    v = views(big, 3)
+    rc = lib.pconv_conv3x3_wino(dummy, dummy, dummy, dummy, 1, cin, h, w, cout, 0, None, None, 0, None, 0, 0,
+                                ctypes.addressof(v), None)
+    assert rc < 0 and b"32-bit byte offsets" in lib.pconv_last_error()
+    # direct kernel: 16 channels per chunk
+    big = (1 << 32) // 60 + 1
+    v = views(big, 4)
+    rc = lib.pconv_conv2d(dummy, dummy, dummy, dummy, 1, cin, h, w, cout, 3, 1, 0, None, None, 0, None, None, 0, 0,
+                          ctypes.addressof(v), None)
+    assert rc < 0 and b"32-bit byte offsets" in lib.pconv_last_error()
+    # the largest stride of the codec (8 frames at 2048x4096: a 1/2-scale 192-channel tile-batch tensor,
+    # channel stride 68 * 2052 floats) is nowhere near the limit
+    assert (15 * 68 * 2052 + 67 * 2052 + 2052) * 4 < (1 << 32)

@@ -142,3 +142,16 @@ def test_split_transforms_equal_frame_by_frame(oracle_backend):
     whole = enc.encoder(t).clone()
     for k in (1, 4, 9):
         assert torch.equal(enc.encoder.forward_range(enc.encoder.forward_range(t, 0, k), k, 10), whole)
+    # a split point at or behind the fused tail is an empty second range: the final conv must not run twice
+    assert torch.equal(enc.encoder.forward_range(enc.encoder.forward_range(t, 0, 10), 10, 10), whole)
+    assert torch.equal(enc.encoder.forward_range(enc.encoder.forward_range(t, 0, 12), 12, 10), whole)
+    # ... and CodecEngine reads out-of-range knobs (PCONV_ANALYSIS_SPLIT / PCONV_SYNTHESIS_SPLIT) as 'no split'
+    eng.ANALYSIS_SPLIT, eng.SYNTHESIS_SPLIT = 10, 12
+    try:
+        assert torch.equal(eng.symbols(x), one_by_one)
+        rec2 = eng.reconstruct(sym, 3)
+        assert torch.equal(rec2, rec)
+        eng.ANALYSIS_SPLIT, eng.SYNTHESIS_SPLIT = 9, 11
+        assert torch.equal(eng.symbols(x), one_by_one) and torch.equal(eng.reconstruct(sym, 3), rec)
+    finally:
+        del eng.ANALYSIS_SPLIT, eng.SYNTHESIS_SPLIT

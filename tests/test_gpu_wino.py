@@ -136,3 +136,46 @@ def test_wino_follows_reloaded_weights(hip_backend, monkeypatch):
     y1 = P().tile_conv2d(m, x, m.weight, m.bias, 1).clone()
     ref = torch.nn.functional.conv2d(x, m.weight, m.bias)
     assert (y1 - ref).abs().max().item() < 1e-4 and (y1 - y0).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("xscale,wscale", [(1e3, 1.0), (1e-3, 1.0), (1.0, 1e3), (1e3, 1e-3), (30.0, 30.0)])
+def test_wino_relative_error_at_other_scales(xscale, wscale, hip_backend, monkeypatch):
+    """A trained model's activations are not unit scale (GDN outputs, attention products): the bound is
+    RELATIVE here.  Inputs x xscale, weights of mixed scale (every fourth output channel x 100, every
+    third input channel x 0.01, on top of wscale), bias 0: against a float64 convolution the error of
+    every output stays under 4e-6 of the layer's output scale sqrt(sum_k w^2 x^2) -- a few ulps of the
+    K = 9 cin terms it sums -- for the Winograd kernel as for the direct fmaf chain, and Winograd is at
+    most 3 x the direct kernel's own error (its transforms add two roundings per operand)."""
+    tn, cin, h, w, cout = 2, 192, 10, 134, 192
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(tn, cin, h, w, generator=g) * xscale
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (wscale / np.sqrt(cin * 9))
+    wt[::4] *= 100.0
+    wt[:, ::3] *= 0.01
+    b = torch.zeros(cout)
+    ref64 = torch.nn.functional.conv2d(x.double(), wt.double())
+    # output scale per (tile, cout, pixel): the l2 norm of the products that are summed
+    scale = torch.nn.functional.conv2d(x.double() ** 2, wt.double() ** 2).sqrt()
+    yd = conv(monkeypatch, "direct", x.to(DEV), wt.to(DEV), b.to(DEV), 1).cpu().double()
+    yw = conv(monkeypatch, "wino", x.to(DEV), wt.to(DEV), b.to(DEV), 1).cpu().double()
+    rd = ((yd - ref64).abs() / scale).max().item()
+    rw = ((yw - ref64).abs() / scale).max().item()
+    assert rd < 4e-6 and rw < 4e-6, "relative error: direct %g, winograd %g" % (rd, rw)
+    assert rw < 3 * rd + 1e-7, "winograd %g vs direct %g" % (rw, rd)
+    assert torch.isfinite(yw).all()
+
+
+def test_wino_fallbacks_are_counted(hip_backend, monkeypatch):
+    """a 3x3 stride-1 layer Winograd was selected for but does not take (cin % 16 != 0, 12 couts) goes to
+    the direct kernel and is counted in PCONV.conv_fallbacks; a layer it takes is not"""
+    monkeypatch.setenv("PCONV_CONV3X3", "wino")
+    P().conv_fallbacks.clear()
+    owner = type("Owner", (), {})()
+    x, wt, b, _ = data(1, 24, 6, 66, 40)
+    P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 1)
+    assert P().conv_fallbacks == {(24, 6, 66, 40, False): 1}
+    x, wt, b, _ = data(1, 96, 6, 66, 96)
+    P().tile_conv2d(type("Owner", (), {})(), x.to(DEV), wt.to(DEV), b.to(DEV), 1)
+    assert len(P().conv_fallbacks) == 1
+    assert P()._native.hip_lib().pconv_wino_supported(8, 6, 66, 96, 0) == 0      # the header's contract: cin % 16
+    assert P()._native.hip_lib().pconv_wino_supported(16, 6, 66, 32, 0) == 1
