@@ -77,8 +77,9 @@ def set_detmath(on):
     lib().orc_set_detmath(ctypes.c_int(1 if on else 0))
 
 
-# entropy-conv summation order: 0 = reference's (128-thread tree), 1 = product's
-CONV_ORDER = 1
+# entropy-conv summation order: 0 = reference's (128-thread tree), 1 = the product's of rounds 1-3 (tap-major,
+# 64 lanes), 2 = the product's since round 4 (causal-compact: only the unmasked entries, by kh + kw, kh, channel)
+CONV_ORDER = 2
 
 
 def _p(t):

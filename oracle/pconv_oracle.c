@@ -954,9 +954,9 @@ void orc_entropy_conv(const float *input, const float *weight, const float *bias
        *     e = 0;  for d in 0..2(k-1):  U = clamp(T - d, 0, ngroup) * group_in,  T = tc + (k-1) + slack
        *               for kh in max(0, d-(k-1)) .. min(k-1, d):  for ci in 0..U-1:  entry e++ = (kh, d-kh, ci)
        * lane e % 64 accumulates its entries in ascending e with fmaf, then the xor butterfly 32..1.
-       * (A masked entry multiplies a weight the reference's conv_mask_v5 / v6 zeroes: leaving it out
-       * adds nothing, and every group's usable set is a PREFIX-free compact list, so a kernel does
-       * ceil(L/64) rounds instead of ceil(25 cin / 64): half of them on average.) */
+       * (A masked entry multiplies a weight the reference's conv_mask_v5 / v6 zeroes: leaving it out adds
+       * nothing, and a kernel that walks only the L usable entries does ceil(L / 64) rounds instead of
+       * ceil(25 cin / 64): half of them on average.) */
       const float *wrow = weight + ((i64)nbatch * nout + pout) * red;
       const int wpad = width + 2 * pad_in;
       const float *base = input + (i64)qn * channel * index_stride + (i64)(th - half_kernel + pad_in) * wpad +

@@ -44,6 +44,11 @@ HIP_FLAGS = [
     "-I" + INCLUDE,
 ]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I" + INCLUDE]
+# per-file additions.  entropy_engine.hip: the band kernels' rounds are 8 LDS reads + 24 independent fmaf
+# chains; the SLP vectoriser pairs the chains into v_pk_fma_f32 (same rate as two v_fma_f32 on gfx950) and pays
+# for it with dozens of register moves at every round boundary (408 fmaf + 89 moves without it, 48 packed
+# fma + 157 moves and a third of the LDS reads re-issued with it)
+FILE_FLAGS = {"entropy_engine.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -88,7 +93,7 @@ def _compile(src, flags, cc, hdr_time, as_hip):
     os.makedirs(objdir, exist_ok=True)
     obj = os.path.join(objdir, src + ".o")
     if _stale(obj, max(os.path.getmtime(path), hdr_time)):
-        cmd = [cc] + flags
+        cmd = [cc] + flags + (FILE_FLAGS.get(src, []) if as_hip else [])
         if as_hip and src.endswith(".cpp"):
             cmd += ["-x", "hip"]
         _run(cmd + ["-c", path, "-o", obj])

@@ -179,3 +179,32 @@ def test_pipelined_decode_equals_plain_decode(hip_backend, monkeypatch):
     assert eng.encode(x) == streams
     monkeypatch.setattr(CodecEngine, "ENCODE_CHUNK", 1)
     assert eng.encode(x) == streams
+
+
+@pytest.mark.parametrize("vd", [112, 192])
+def test_engine_wide_models_equal_per_op_path(vd, hip_backend, tmp_path):
+    """The other model widths of the reference's tables (valid_dim 112 / 192: 28 / 48 channel groups,
+    pseudo_codec.py:18-23): the band kernels' instantiations for 28 / 84 and 48 / 144 input channels (weights
+    in several register chunks, group slabs fetched from global memory in the bulk pass) write the stream the
+    op-by-op loop writes, and decode it back to the symbols -- 1280 x 512 frames: 10 symbol rows per tile = two
+    row chunks of the step kernel (8 + 2), and a two-frame lock-step group."""
+    from pseudocylindrical_convolution_amd import pseudo_codec as PC
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    torch.manual_seed(4321)
+    enc, dec = PC.PseudoEncoder(vd, 0).eval(), PC.PseudoDecoder(vd, 0).eval()
+    g = torch.Generator().manual_seed(17)
+    sd = {k: torch.randn(v.shape, generator=g) * 0.03 for k, v in enc.ent.state_dict().items()}
+    enc.ent.load_state_dict(sd)
+    dec.ent.load_state_dict(sd)
+    dec.quant.weight.data.copy_(enc.quant.weight.data)
+    eng = CodecEngine(vd, 0, enc, dec)
+    x = _frames(2, 1280, 512, seed=13)
+    streams = eng.encode(x)
+    path = str(tmp_path / "perop.bin")
+    enc.forward_per_op(x[:1], path)
+    with open(path, "rb") as f:
+        assert streams[0] == f.read()
+    sym = eng.symbols(x)
+    assert tuple(sym.shape) == (32, vd // 4, 10, 64)
+    assert torch.equal(eng._engine("dec", 10, 64, 2).decode(streams), sym)
+    assert torch.equal(eng._engine("dec", 10, 64, 1).decode(streams[1:]), sym[16:])

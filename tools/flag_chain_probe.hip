@@ -1,22 +1,29 @@
 // What does a dependency between two "layers" of the entropy decoder cost when it is NOT a kernel
-// launch?  (SURVEY 8f-1 / DESIGN 5: the persistent step kernel was priced from the guide's GRID
-// barrier; the dependency is neighbour-to-neighbour, i.e. point-to-point flags, which this measures.)
+// launch?  (SURVEY 8f-1 / DESIGN 5.)
 //
-// A step of the decoder is LAYERS dependent stages; stage l of step s may start when stage l-1 of
-// step s is complete (stage 0: when the last stage of step s-1 is).  Three ways to run STEPS x LAYERS
-// stages of PARTS workgroups each, all doing the same token work (read two values the previous stage
-// wrote -- its own part's and a neighbour's -- add, write; optionally spin `work` cycles):
+// A step of the decoder is LAYERS dependent stages; stage l of step s needs stage l-1 of step s (stage 0:
+// the last stage of step s-1) -- but only ITS NEIGHBOURHOOD of it: a position's 5 x 5 window reads what the
+// workgroups of the parts next to it wrote.  STEPS x LAYERS stages of PARTS parts each, every part doing the
+// same token work (read the three values its own part and its two neighbours wrote in the previous stage,
+// add, write; optionally spin `work` cycles), four ways:
 //
-//   launch    one kernel launch per stage, in one stream (what the engine does today)
-//   flags     ONE persistent kernel of LAYERS x PARTS workgroups; a stage's workgroups bump a device
-//             counter (release, agent scope) when done and the next stage's poll it (acquire)
-//   flags1x   the same with every workgroup on ONE XCD (workgroups are dealt to the 8 XCDs round-robin
-//             by block index: the grid is 8 x larger and only blocks with index % 8 == 0 take part),
-//             so that no flag or datum crosses an L2 boundary
+//   launch    one kernel launch per stage, in one stream (what the engine does)
+//   p2p       ONE persistent kernel; part p of stage l waits for the flags of parts p-1, p, p+1 of the
+//             previous stage only -- every flag a monotonic step count on a 64-byte line of its own, written
+//             by one lane after plain stores + an agent-scope release fence + s_waitcnt, polled with relaxed
+//             loads and s_sleep back-off, one agent-scope acquire fence after the three have matched
+//             (MI355X_MICROARCH.md, "Valid forms").  No counter is shared by more than three pollers.
+//   central   the round-3 probe: one counter per layer that every part of the stage bumps and every part
+//             of the next stage polls (a central barrier, NOT point-to-point -- the round-3 write-up called
+//             it "flags")
+//   p2p1x     p2p with every workgroup on ONE XCD (blocks are dealt to the XCDs round-robin: the grid is
+//             8 x larger and only blocks with index % 8 == 0 take part)
 //
-// The data check (every value of the last stage against the closed form computed on the host) makes
-// sure the flags really order the stages' memory traffic.  Every wait is bounded: a workgroup that
-// polls for more than ~2 s raises an error word and everything drains.
+// Grids larger than the chip holds (12 x 1300 parts) give every workgroup a contiguous range of parts of its
+// layer.  The data check (every value of the last stage against the recurrence run on the host) makes sure
+// the flags really order the memory traffic: values live in a ring of two steps, so a slot is rewritten
+// only after its three readers -- which lie in the writer's dependency cone -- are done.  Every wait is
+// bounded: a workgroup that polls for more than ~2 s raises an error word and everything drains.
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/flag_chain_probe.hip -o tools/_build/flag_chain_probe
 #include <hip/hip_runtime.h>
@@ -27,6 +34,7 @@
 
 namespace {
 constexpr int kThreads = 256;
+constexpr int kFlagStride = 16;  // uint32 per flag: 64-byte lines
 
 __device__ __forceinline__ void spin_cycles(long long cycles) {
   if (cycles <= 0) return;
@@ -35,9 +43,8 @@ __device__ __forceinline__ void spin_cycles(long long cycles) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
 }
 
-// value of (layer l, part p) of step s from the previous stage's values
 __device__ __forceinline__ uint32_t stage_value(const uint32_t *prev, int p, int parts) {
-  return prev[p] + prev[(p + 1) % parts] + 1u;
+  return prev[(p + parts - 1) % parts] + prev[p] + prev[(p + 1) % parts] + 1u;
 }
 
 __global__ __launch_bounds__(kThreads) void stage_kernel(const uint32_t *__restrict__ prev, uint32_t *__restrict__ cur,
@@ -47,48 +54,75 @@ __global__ __launch_bounds__(kThreads) void stage_kernel(const uint32_t *__restr
   if (threadIdx.x == 0) cur[p] = stage_value(prev, p, parts);
 }
 
-// buffers: val[(LAYERS + 1) ring slots][parts]; slot of (step s, layer l) = global stage index % ring
-__global__ __launch_bounds__(kThreads) void persistent_kernel(uint32_t *val, unsigned *done, unsigned *error, int layers,
-                                                              int parts, int steps, long long work, int xcd_stride) {
+// val[2 * layers slots][parts]: slot of global stage g = g % (2 * layers); flag[(l * parts + p) * kFlagStride] =
+// steps part p of layer l has completed.  central != 0: done[l * 32] counts the parts of layer l instead.
+__global__ __launch_bounds__(kThreads) void persistent_kernel(uint32_t *val, unsigned *flag, unsigned *done, unsigned *error,
+                                                              int layers, int parts, int steps, long long work,
+                                                              int xcd_stride, int wg_per_layer, int central) {
   int b = blockIdx.x;
   if (xcd_stride > 1) {
     if (b % xcd_stride) return;  // not on the chosen XCD
     b /= xcd_stride;
   }
-  const int l = b / parts, p = b % parts;
+  const int l = b / wg_per_layer, slice = b % wg_per_layer;
+  const int per = (parts + wg_per_layer - 1) / wg_per_layer;
+  const int p_lo = slice * per, p_hi = p_lo + per < parts ? p_lo + per : parts;
   __shared__ int bail;
   if (threadIdx.x == 0) bail = 0;
   __syncthreads();
-  const int ring = layers + 1;
+  const int ring = 2 * layers;
   for (int s = 0; s < steps; s++) {
-    const long long stage = (long long)s * layers + l;  // global index of this stage; stage -1 = the initial values
-    if (threadIdx.x == 0) {
-      if (stage > 0) {
-        // the previous stage is complete when its counter has seen all its parts
-        const long long prev = stage - 1;
-        const int pl = (int)(prev % layers);
-        const unsigned want = (unsigned)((prev / layers + 1) * parts);
+    const long long stage = (long long)s * layers + l;
+    const int pl = l == 0 ? layers - 1 : l - 1;           // producing layer
+    const unsigned want = l == 0 ? (unsigned)s : (unsigned)(s + 1);  // steps it must have completed
+    for (int p = p_lo; p < p_hi; p++) {
+      if (threadIdx.x == 0 && stage > 0) {
         long long spins = 0;
-        while (__hip_atomic_load(&done[pl * 32], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 1023) == 0 &&
-              (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > (1ll << 24))) {
-            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bail = 1;
-            break;
+        if (central) {
+          const unsigned all = want * (unsigned)parts;
+          while (__hip_atomic_load(&done[pl * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < all) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023) == 0 &&
+                (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > (1ll << 24))) {
+              __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bail = 1;
+              break;
+            }
+          }
+        } else {
+          for (int d = -1; d <= 1 && !bail; d++) {
+            const int q = (p + d + parts) % parts;
+            const unsigned *f = flag + ((size_t)pl * parts + q) * kFlagStride;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+              __builtin_amdgcn_s_sleep(1);
+              if ((++spins & 1023) == 0 &&
+                  (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > (1ll << 24))) {
+                __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bail = 1;
+                break;
+              }
+            }
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-    }
-    __syncthreads();
-    if (bail) return;  // uniform
-    spin_cycles(work);
-    if (threadIdx.x == 0) {
-      const uint32_t *prev = val + ((stage + ring - 1) % ring) * parts;  // slot of stage - 1 (stage 0: the initial values, slot ring-1)
-      uint32_t *cur = val + (stage % ring) * parts;
-      // (the acquire above makes the previous stage's stores visible; these are plain accesses)
-      cur[p] = stage_value(prev, p, parts);
-      __hip_atomic_fetch_add(&done[l * 32], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (bail) return;  // uniform
+      spin_cycles(work);
+      if (threadIdx.x == 0) {
+        const uint32_t *prev = val + ((stage + ring - 1) % ring) * parts;  // stage 0 of step 0: the initial values in slot ring-1
+        uint32_t *cur = val + (stage % ring) * parts;
+        cur[p] = stage_value(prev, p, parts);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (central)
+          __hip_atomic_fetch_add(&done[l * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          __hip_atomic_store(flag + ((size_t)l * parts + p) * kFlagStride, (unsigned)(s + 1), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -102,12 +136,11 @@ __global__ __launch_bounds__(kThreads) void persistent_kernel(uint32_t *val, uns
     }                                                                             \
   } while (0)
 
-// host closed form: run the recurrence
 std::vector<uint32_t> expected(int layers, int parts, int steps) {
   std::vector<uint32_t> a(parts), b(parts);
   for (int p = 0; p < parts; p++) a[p] = (uint32_t)p;
   for (long long st = 0; st < (long long)steps * layers; st++) {
-    for (int p = 0; p < parts; p++) b[p] = a[p] + a[(p + 1) % parts] + 1u;
+    for (int p = 0; p < parts; p++) b[p] = a[(p + parts - 1) % parts] + a[p] + a[(p + 1) % parts] + 1u;
     a.swap(b);
   }
   return a;
@@ -120,15 +153,17 @@ int main(int argc, char **argv) {
   int failed = 0;
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
+  const int max_wg = prop.multiProcessorCount * 8;  // co-resident 256-thread workgroups
   printf("# %s, %d CUs; %d layers x %d steps; token work per stage, workgroups of %d threads\n", prop.name,
          prop.multiProcessorCount, layers, steps, kThreads);
-  printf("# %-8s %6s %10s %14s %12s\n", "mode", "parts", "work(cyc)", "us/stage", "check");
-  for (int parts : {16, 42, 168}) {
+  printf("# %-8s %6s %8s %10s %14s %12s\n", "mode", "parts", "wg/layer", "work(cyc)", "us/stage", "check");
+  for (int parts : {16, 42, 168, 1300}) {
     for (long long work : {0ll, 8000ll}) {  // 8000 cycles ~ 3.3 us: a layer's own work at one frame
-      const int ring = layers + 1;
+      const int ring = 2 * layers;
       uint32_t *val;
-      unsigned *done, *error;
+      unsigned *flag, *done, *error;
       CHECK(hipMalloc(&val, (size_t)ring * parts * 4));
+      CHECK(hipMalloc(&flag, (size_t)layers * parts * kFlagStride * 4));
       CHECK(hipMalloc(&done, layers * 32 * 4));
       CHECK(hipMalloc(&error, 4));
       std::vector<uint32_t> init(parts);
@@ -137,14 +172,19 @@ int main(int argc, char **argv) {
       hipEvent_t e0, e1;
       CHECK(hipEventCreate(&e0));
       CHECK(hipEventCreate(&e1));
-      for (int mode = 0; mode < 3; mode++) {
-        if (mode == 2 && layers * parts > 32 * 8) {
-          // one XCD holds 32 CUs x 8 workgroups of this size: the large grid does not fit one XCD
-          printf("  %-8s %6d %10lld %14s %12s\n", "flags1x", parts, work, "-", "(does not fit one XCD)");
+      const char *names[4] = {"launch", "p2p", "central", "p2p1x"};
+      for (int mode = 0; mode < 4; mode++) {
+        // persistent modes: every workgroup must be resident (they wait for each other)
+        int wg_per_layer = parts;
+        const int budget = (mode == 3 ? max_wg / 8 : max_wg) * 3 / 4;  // margin: never rely on the last slot
+        while (layers * wg_per_layer > budget) wg_per_layer = (wg_per_layer + 1) / 2;
+        if (mode == 3 && parts > 42) {
+          printf("  %-8s %6d %8s %10lld %14s %12s\n", names[mode], parts, "-", work, "-", "(skipped)");
           continue;
         }
         CHECK(hipMemset(val, 0, (size_t)ring * parts * 4));
         CHECK(hipMemcpy(val + (size_t)(ring - 1) * parts, init.data(), parts * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemset(flag, 0, (size_t)layers * parts * kFlagStride * 4));
         CHECK(hipMemset(done, 0, layers * 32 * 4));
         CHECK(hipMemset(error, 0, 4));
         CHECK(hipDeviceSynchronize());
@@ -154,9 +194,9 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(stage_kernel, dim3(parts), dim3(kThreads), 0, 0, val + ((st + ring - 1) % ring) * parts,
                                val + (st % ring) * parts, parts, work);
         } else {
-          const int stride = mode == 2 ? 8 : 1;
-          hipLaunchKernelGGL(persistent_kernel, dim3(layers * parts * stride), dim3(kThreads), 0, 0, val, done, error,
-                             layers, parts, steps, work, stride);
+          const int stride = mode == 3 ? 8 : 1;
+          hipLaunchKernelGGL(persistent_kernel, dim3(layers * wg_per_layer * stride), dim3(kThreads), 0, 0, val, flag, done,
+                             error, layers, parts, steps, work, stride, wg_per_layer, mode == 2 ? 1 : 0);
         }
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
@@ -170,11 +210,12 @@ int main(int argc, char **argv) {
         int bad = 0;
         for (int p = 0; p < parts; p++) bad += got[p] != want[p];
         failed += (bad != 0) || err;
-        printf("  %-8s %6d %10lld %14.3f %12s\n", mode == 0 ? "launch" : (mode == 1 ? "flags" : "flags1x"), parts, work,
+        printf("  %-8s %6d %8d %10lld %14.3f %12s\n", names[mode], parts, mode == 0 ? parts : wg_per_layer, work,
                ms * 1e3 / ((double)steps * layers), err ? "TIMED OUT" : (bad ? "WRONG DATA" : "ok"));
         fflush(stdout);
       }
       CHECK(hipFree(val));
+      CHECK(hipFree(flag));
       CHECK(hipFree(done));
       CHECK(hipFree(error));
     }
