@@ -77,9 +77,10 @@ def set_detmath(on):
     lib().orc_set_detmath(ctypes.c_int(1 if on else 0))
 
 
-# entropy-conv summation order: 0 = reference's (128-thread tree), 1 = the product's of rounds 1-3 (tap-major,
-# 64 lanes), 2 = the product's since round 4 (causal-compact: only the unmasked entries, by kh + kw, kh, channel)
-CONV_ORDER = 2
+# entropy-conv summation order: 0 = the reference's (128-thread tree), 1 = the product's (tap-major, 64 lanes:
+# what the engine, the per-op kernel and every stream use), 2 = the causal-compact order of the round-4
+# experiment (only the unmasked entries, by kh + kw, kh, channel: tools/experiments/)
+CONV_ORDER = 1
 
 
 def _p(t):

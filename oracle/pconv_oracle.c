@@ -949,7 +949,8 @@ void orc_entropy_conv(const float *input, const float *weight, const float *bias
       }
       sum = reduce_ref128(part);
     } else if (order == 2) {
-      /* The product's order since round 4 ("causal-compact"): only the entries the causal mask lets
+      /* The "causal-compact" order of the round-4 band-kernel experiment (built, parity-green on the GPU,
+       * measured, not adopted: DESIGN.md section 5): only the entries the causal mask lets
        * through are enumerated -- by window anti-diagonal d = kh + kw, then kh, then input channel:
        *     e = 0;  for d in 0..2(k-1):  U = clamp(T - d, 0, ngroup) * group_in,  T = tc + (k-1) + slack
        *               for kh in max(0, d-(k-1)) .. min(k-1, d):  for ci in 0..U-1:  entry e++ = (kh, d-kh, ci)

@@ -44,11 +44,7 @@ HIP_FLAGS = [
     "-I" + INCLUDE,
 ]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I" + INCLUDE]
-# per-file additions.  entropy_engine.hip: the band kernels' rounds are 8 LDS reads + 24 independent fmaf
-# chains; the SLP vectoriser pairs the chains into v_pk_fma_f32 (same rate as two v_fma_f32 on gfx950) and pays
-# for it with dozens of register moves at every round boundary (408 fmaf + 89 moves without it, 48 packed
-# fma + 157 moves and a third of the LDS reads re-issued with it)
-FILE_FLAGS = {"entropy_engine.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {}  # per-file additions to HIP_FLAGS (none at present)
 
 
 def hipcc():

@@ -47,8 +47,8 @@ struct EeGeom {
   const float *vh_wgt;
   const EePos *pos;         // device, one record per schedule entry
   const EeHalo *halo;       // device, reverse halo records (EePos::rev indexes them)
-  const int32_t *pix_rev;   // device, per unpadded pixel (tile*h + row)*w + col: EePos::rev of that position
-                            // (the band kernels find their positions by geometry, not through the schedule)
+  const uint32_t *tap_in, *tap_hid;  // device, byte offset of reduction entry kk inside a window of the
+                                     // context (ngroup channels) / of a hidden layer (3*ngroup), 0 past the end
   // bulk (encoder) mode: every (plane, group) pair at once
   const int32_t *pos_plane;  // device, plane of every schedule entry
   const int32_t *step_row;   // device, first table row of every step (rows are [step][img][l])
@@ -57,29 +57,23 @@ struct EeGeom {
 
 // reduction entries of a slab, padded to whole waves
 static inline int ee_slab_slots(int cin) { return (cin * 25 + 63) / 64 * 64; }
-// weights (3, cout, cin, 5, 5) -> per (set, output group) a slab [slot][4] in the group's CAUSAL-COMPACT
-// order (entropy_engine.hip): only the entries the causal mask lets through -- tap (kh, kw) of input
-// channel ci is usable by output group tc iff ci < (tc + slack + 4 - kh - kw)*(cin/ngroup), slack = 0 for
-// the input layer (constrain 5), 1 for the hidden ones (constrain 6) -- enumerated by kh + kw, then kh, then
-// ci; a slot holds the group's 3 weights of the entry and, as int bits, kh << 16 | (kw*cin + ci); the slots
-// past the group's entry count are zeros
+// weights (3, cout, cin, 5, 5) -> per (set, output group) a slab [slot][4], slot = tap*cin + ci,
+// holding the group's 3 rows interleaved (4th float: padding) with the CAUSAL MASK of the
+// group applied (masked taps and the slots past the reduction length are zeros): tap (kh, kw)
+// of input channel ci is usable by output group tc iff ci < (tc + slack + 4 - kh - kw)*(cin/ngroup),
+// slack = 0 for the input layer (constrain 5), 1 for the hidden ones (constrain 6)
 static inline size_t ee_packed_floats(int nset, int cout, int cin) {
   return (size_t)nset * (cout / 3) * ee_slab_slots(cin) * 4;
 }
 int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
                    void *stream);
 
-// Every buffer a band kernel READS (ctx, act[l]) must be allocated with EE_GUARD_BYTES of addressable memory
-// in front of and behind it: a band row is staged as one contiguous run that may begin left of its tile row
-// or end right of it (columns no existing position reads).
-#define EE_GUARD_BYTES (32 * 1024)
-
 // one layer of one step.  x: cin channels, padded by 2; y: cout channels, padded
 // by pad_out.  shared_input: x holds nimg images that every replica reads
 // (layer 0), otherwise 3*nimg.  Output group of plane p is psum - p.
 int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
             const float *slope, const float *residual, float *y, int cin, int cout, int constrain,
-            int pad_out, int first_plane, int nplane, int psum, void *stream);
+            int pad_out, int first_plane, int nplane, int longest_plane, int psum, void *stream);
 // the same layer for ALL (plane, group) pairs at once (encoder: every symbol is
 // known, the causal masks make each output equal to the step-by-step one)
 int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,

@@ -180,7 +180,7 @@ struct pconv_entropy_engine {
   int32_t *widths_d = nullptr, *order_d = nullptr, *sched_start_d = nullptr, *vh_col = nullptr;
   EePos *pos_d = nullptr;
   EeHalo *halo_d = nullptr;
-  int32_t *pix_rev_d = nullptr;
+  uint32_t *tap_in_d = nullptr, *tap_hid_d = nullptr;
   float *vh_wgt = nullptr;
   int32_t *pos_plane_d = nullptr;
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
@@ -213,18 +213,6 @@ struct pconv_entropy_engine {
     return {sched_start[st], sched_start[end] - sched_start[st], st, end - st};
   }
 
-  static hipError_t guarded_alloc(float **p, size_t bytes) {
-    char *raw = nullptr;
-    hipError_t e = hipMalloc(&raw, bytes + 2 * EE_GUARD_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipMemset(raw, 0, bytes + 2 * EE_GUARD_BYTES);
-    *p = reinterpret_cast<float *>(raw + EE_GUARD_BYTES);
-    return e;
-  }
-  static void guarded_free(float *p) {
-    if (p) (void)hipFree(reinterpret_cast<char *>(p) - EE_GUARD_BYTES);
-  }
-
   int init_group(Group &g, int first, int n, const EeGeom &base) {
     g.nimg = n;
     g.first = first;
@@ -242,9 +230,8 @@ struct pconv_entropy_engine {
     HIP_TRY(hipMalloc(&g.step_row_d, g.step_row.size() * 4));
     HIP_TRY(hipMemcpy(g.step_row_d, g.step_row.data(), g.step_row.size() * 4, hipMemcpyHostToDevice));
     g.geom.step_row = g.step_row_d;
-    // (guard bands: the band kernels stage rows that may begin in front of / end behind the buffer)
-    HIP_TRY(guarded_alloc(&g.ctx, ctx_elems(n) * 4));
-    for (int l = 0; l < kLayers; l++) HIP_TRY(guarded_alloc(&g.act[l], act_elems(l, n) * 4));
+    HIP_TRY(hipMalloc(&g.ctx, ctx_elems(n) * 4));
+    for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&g.act[l], act_elems(l, n) * 4));
     const size_t all_rows = sym_per_img * n;
     HIP_TRY(hipMalloc(&g.tables_d, all_rows * (nlevels + 1) * 4));
     HIP_TRY(hipMalloc(&g.labels_d, all_rows * 4));
@@ -355,14 +342,21 @@ struct pconv_entropy_engine {
       }
       HIP_TRY(hipMalloc(&pos_d, pos.size() * sizeof(EePos)));
       HIP_TRY(hipMemcpy(pos_d, pos.data(), pos.size() * sizeof(EePos), hipMemcpyHostToDevice));
-      // the same `rev` per unpadded pixel, for the band kernels
-      std::vector<int32_t> pix_rev((size_t)rows * w, 0);
-      for (int i = 0; i < npos; i++) pix_rev[order[i]] = pos[i].rev & 15 ? pos[i].rev : 0;
-      HIP_TRY(hipMalloc(&pix_rev_d, pix_rev.size() * 4));
-      HIP_TRY(hipMemcpy(pix_rev_d, pix_rev.data(), pix_rev.size() * 4, hipMemcpyHostToDevice));
+      // byte offset of reduction entry kk = tap*cin + ci inside a 5 x 5 x cin window
+      for (int pass = 0; pass < 2; pass++) {
+        const int cin = pass == 0 ? ngroup : 3 * ngroup;
+        std::vector<uint32_t> tap(ee_slab_slots(cin), 0u);
+        for (int kk = 0; kk < cin * 25; kk++) {
+          const int t5 = kk / cin, ci = kk - t5 * cin;
+          tap[kk] = 4u * (uint32_t)(((t5 / 5) * win + t5 % 5) * cin + ci);
+        }
+        uint32_t **dst = pass == 0 ? &tap_in_d : &tap_hid_d;
+        HIP_TRY(hipMalloc(dst, tap.size() * 4));
+        HIP_TRY(hipMemcpy(*dst, tap.data(), tap.size() * 4, hipMemcpyHostToDevice));
+      }
     }
     EeGeom base = {npart, ngroup, h, w, nimg, widths_d, order_d, sched_start_d, vh_col, vh_wgt, pos_d,
-                   halo_d, pix_rev_d, nullptr, nullptr, 0};
+                   halo_d, tap_in_d, tap_hid_d, nullptr, nullptr, 0};
     {  // bulk (encoder) maps
       const int npos = sched_start[rows + w - 1];
       std::vector<int32_t> pp(npos);
@@ -400,11 +394,11 @@ struct pconv_entropy_engine {
       if (p) (void)hipFree(p);
     };
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
-    freed(pos_plane_d); freed(pos_d); freed(halo_d); freed(pix_rev_d);
+    freed(pos_plane_d); freed(pos_d); freed(halo_d); freed(tap_in_d); freed(tap_hid_d);
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
     for (Group &g : groups) {
-      guarded_free(g.ctx); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
-      for (int l = 0; l < kLayers; l++) guarded_free(g.act[l]);
+      freed(g.ctx); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
+      for (int l = 0; l < kLayers; l++) freed(g.act[l]);
       if (g.tables_h) (void)hipHostFree(g.tables_h);
       if (g.labels_h) (void)hipHostFree(g.labels_h);
       if (g.packed_h) (void)hipHostFree(g.packed_h);
@@ -449,7 +443,7 @@ struct pconv_entropy_engine {
       // second conv of a residual block: += block input, folded into the epilogue
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
       PC_TRY(ee_conv(&g.geom, in, l == 0, lw[l], lb[l], la[l], res, g.act[l], layer_cin(l), hid, l == 0 ? 5 : 6,
-                     l == kLayers - 1 ? 0 : kPad, cur.first, cur.nplane, s, g.stream));
+                     l == kLayers - 1 ? 0 : kPad, cur.first, cur.nplane, longest_plane, s, g.stream));
     }
     return PCONV_OK;
   }

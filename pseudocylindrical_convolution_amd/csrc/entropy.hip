@@ -166,13 +166,13 @@ __global__ __launch_bounds__(kBlock) void dextract2_kernel(
 // Work decomposition: a workgroup owns kPosPerWg positions of ONE plane of ONE
 // image, one per wave; they share the output group (tc = psum - plane) and
 // therefore the GO x (cin*25) weight rows, which are staged in LDS once per
-// workgroup while the gathers are in flight.  Reduction order (part of the bitstream
-// contract; the engine's band kernels and the oracle, order 2, restate it) -- the
-// CAUSAL-COMPACT order: only the entries the causal mask lets through are enumerated,
-// by window anti-diagonal d = kh + kw, then kh, then input channel,
-//     e = 0;  for d in 0..8:  U = clamp(tc + 4 + slack - d, 0, ngroup) * group_in
-//               for kh in max(0, d-4) .. min(4, d):  for ci in 0..U-1:  entry e++ = (kh, d - kh, ci)
-// lane l accumulates e = l, l+64, ... with fmaf, then v += shfl_xor(v, 32, 16, 8, 4, 2, 1).
+// workgroup while the gathers are in flight.  Lanes stride over the flattened
+// reduction index kk = (kh*5 + kw)*cin + ci (tap-major, channel-minor: the order
+// in which the engine's channels-last buffers are contiguous), keep GO partial
+// sums and finish with a butterfly.  Reduction order (part of the bitstream
+// contract, restated by the oracle): lane l accumulates kk = l, l+64, ... with
+// fmaf, skipping taps the causal mask forbids, then
+// v += shfl_xor(v, 32, 16, 8, 4, 2, 1).
 // All ITER gathers of a lane are issued before the first fmaf (the step is
 // latency-bound); weights come from LDS (consecutive lanes, conflict-free).
 //
@@ -186,25 +186,6 @@ __global__ __launch_bounds__(kBlock) void dextract2_kernel(
 // scalar with a warp-32 shuffle tail; not translatable to wave64).
 constexpr int kConvBlock = 512;                 // 8 waves, one position each
 constexpr int kPosPerWg = kConvBlock / kWave;
-
-// compact entry e of a group with threshold T = tc + 4 + slack -> (kh, kw, ci); false past the last entry
-__device__ __forceinline__ bool compact_entry(int e, int T, int ngroup, int group_in, int &kh, int &kw, int &ci) {
-  for (int d = 0; d <= 8; d++) {
-    int ug = T - d;
-    ug = ug > ngroup ? ngroup : ug;
-    if (ug <= 0) break;
-    const int U = ug * group_in, kh0 = d < 5 ? 0 : d - 4, ntap = d < 5 ? d + 1 : 9 - d;
-    if (e < ntap * U) {
-      kh = kh0 + e / U;
-      ci = e % U;
-      kw = d - kh;
-      return true;
-    }
-    e -= ntap * U;
-  }
-  kh = kw = ci = 0;
-  return false;
-}
 
 struct VHalo {
   const int32_t *widths, *col;
@@ -253,10 +234,8 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
   const int slack = (constrain == 5) ? 0 : 1;
   const int qn = pn * npart + p.tg;
   const float *ximg = x + (size_t)pn * npart * tile_stride;
-  const int T = tc + 2 * HALF + slack, ngroup = cin / group_in;
   float xv[ITER];
   bool ok[ITER];
-  int kc[ITER];  // where the entry's weight sits in the tap-major LDS rows
   bool edge = false;
   int valid = 0;
   if (VHALO) {
@@ -267,11 +246,14 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
     const float *xin = ximg + (size_t)p.tg * tile_stride + (size_t)(p.th - HALF + pad_in) * win + p.tw - HALF + pad_in;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
+      const int kk = lane + it * kWave;
+      const int kc = kk < red ? kk : red - 1;
+      const int ci = kc % cin, tap = kc / cin;
+      const int kw = tap % K, kh = tap / K;
       // causality: input group g at (qh, pw) is usable iff g + qh + pw < psum
       // (constrain 5) or <= psum (constrain 6); qh + pw = row + tw - 4 + kh + kw
-      int kh, kw, ci;
-      ok[it] = compact_entry(lane + it * kWave, T, ngroup, group_in, kh, kw, ci) && active;
-      kc[it] = (kh * K + kw) * cin + ci;
+      const int nch = (tc + 2 * HALF - kh - kw + slack) * group_in;
+      ok[it] = active && (kk < red) && (ci < nch);
       xv[it] = ok[it] ? xin[(size_t)ci * in_plane + kh * win + kw] : 0.f;
     }
   } else {
@@ -281,9 +263,12 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
     float src_w[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
-      int kh, kw, ci;
-      ok[it] = compact_entry(lane + it * kWave, T, ngroup, group_in, kh, kw, ci) && active;
-      kc[it] = (kh * K + kw) * cin + ci;
+      const int kk = lane + it * kWave;
+      const int kc = kk < red ? kk : red - 1;
+      const int ci = kc % cin, tap = kc / cin;
+      const int kw = tap % K, kh = tap / K;
+      const int nch = (tc + 2 * HALF - kh - kw + slack) * group_in;
+      ok[it] = active && (kk < red) && (ci < nch);
       src_off[it] = -1;
       src_off1[it] = -1;
       src_w[it] = 1.f;
@@ -331,9 +316,11 @@ __global__ __launch_bounds__(kConvBlock) void entropy_conv_kernel(
   for (int o = 0; o < GO; o++) acc[o] = 0.f;
 #pragma unroll
   for (int it = 0; it < ITER; it++) {
+    const int kk = lane + it * kWave;
+    const int kc = kk < red ? kk : red - 1;
 #pragma unroll
     for (int o = 0; o < GO; o++) {
-      const float f = fmaf(xv[it], wl[o * red + kc[it]], acc[o]);
+      const float f = fmaf(xv[it], wl[o * red + kc], acc[o]);
       acc[o] = ok[it] ? f : acc[o];
     }
   }

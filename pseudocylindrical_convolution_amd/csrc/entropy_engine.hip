@@ -1,10 +1,11 @@
 // Channels-last kernels of the native entropy engine (see ee_kernels.h).
 //
 // Same arithmetic as the per-op kernels of entropy.hip (the streams must be
-// byte-identical), different memory layout: with [tile][row][col][C] storage a row of
-// the 5 x 5 x C windows of neighbouring positions is ONE contiguous run, so the band
-// kernels below stage whole diagonals of windows in LDS with kilobyte LDS-DMA pieces
-// (rounds 1-3: 64-lane 4-byte gathers per window, bound by the L2 -> register path).
+// byte-identical), different memory layout: with [tile][row][col][C] storage the
+// 5 x 5 x C window of a position is 5 contiguous runs, and the reduction index
+// kk = tap*C + ci walks memory in order, so a wave's 64 gathers hit 2-3 cache
+// lines instead of ~13 with NCHW (the per-op layout), where this step kernel is
+// bound by the number of cache lines the texture path has to look up.
 //
 // Halos are written by the producer of the interior value they derive from (see
 // ee_kernels.h): the causal rule of pconv_host_causal_table (what
@@ -12,7 +13,6 @@
 // applied in the epilogue of the kernel that computes the value, so consumers
 // read plain padded windows.
 #include <stdlib.h>
-#include <atomic>
 #include "common.h"
 #include "ee_kernels.h"
 #include "gmm_device.h"
@@ -20,6 +20,11 @@
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kConvBlock = 256;   // step kernel: 4 waves, one wavefront position per wave at a time
+constexpr int kPosPerWave = 4;    // positions a wave walks with its weights in registers (measured best of 1..8)
+// register cap of the step kernel: weights + offsets + window = 5 registers per tap
+// and lane, so wider layers get fewer, fatter waves
+constexpr int waves_per_eu(int iter) { return iter <= 20 ? 4 : (iter <= 40 ? 2 : 1); }
 constexpr int K = 5, KK = 25, HALF = 2, PAD = 2, GO = 3;
 
 struct Pos {
@@ -34,11 +39,52 @@ __device__ __forceinline__ Pos decode_pos(int hw, int h, int w) {
   return p;
 }
 
-// The canonical butterfly of the masked convolution -- v[l] + v[l ^ off] for off = 32, 16, 8, 4, 2, 1: every
-// lane ends with the same total, bit for bit what __shfl_xor gives (each step adds the same two numbers) --
-// for 12 values at once (4 positions x 3 outputs), on the cross-lane VALU paths of gfx950 instead of
-// ds_bpermute round trips: half / row swaps, a row rotate, one ds_swizzle (xor 4 has no DPP form), two quad
-// permutes.  A plain butterfly repeats every exchange in both partners; here a step keeps each
+// v[l] + v[l ^ off] for off = 32, 16, 8, 4, 2, 1 -- the canonical butterfly of the
+// masked convolution (every lane ends with the same total, bit for bit what
+// __shfl_xor gives: each step adds the same two numbers) -- on the cross-lane
+// VALU paths of gfx950 instead of six ds_bpermute round trips: half / row swaps,
+// a row rotate, one ds_swizzle (xor 4 has no DPP form) and two quad permutes.
+__device__ __forceinline__ float butterfly_sum(float v) {
+  {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));                      // xor 4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad [1,0,3,2]
+  return v;
+}
+
+// The three outputs of one position in one packed butterfly: 7 exchange-adds instead
+// of 18, same pairs and order per value.  Result per lane: the total of output
+// {0, 2, 1, 2}[lane >> 4] (rows of 16 lanes).
+__device__ __forceinline__ float butterfly3(float v0, float v1, float v2) {
+  float a01, a2;
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+    a01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lanes 0-31: v0, lanes 32-63: v1
+    const unsigned u = __float_as_uint(v2);
+    auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a2 = __uint_as_float(q[0]) + __uint_as_float(q[1]);   // v2 in both halves
+  }
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a01), __float_as_uint(a2), false, false);
+  float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows: v0, v2, v1, v2
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // xor 8
+  t += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t), 0x101F));                      // xor 4
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));   // xor 2
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));   // xor 1
+  return t;
+}
+
+// The same butterfly for 12 values at once (4 positions x 3 outputs of the bulk kernel).
+// A plain butterfly repeats every exchange in both partners; here a step keeps each
 // pair's sum in only one of them and uses the freed half for another value, so the 12
 // reductions take 6 + 3 + 2 + 1 + 1 + 1 exchange-adds instead of 72.  Every value still
 // goes through the pairs (l, l^32), (l, l^16), ... (l, l^1) in that order -- the sums
@@ -76,68 +122,61 @@ __device__ __forceinline__ float butterfly12(const float (&v)[4][GO], int lane) 
   return t;
 }
 
-// ---- the causal-compact reduction order (round 4) ---------------------------------------------------
-//
-// The causal mask lets output group tc use window entry (kh, kw, input channel ci) iff
-//     ci / group_in + kh + kw < T,   T = tc + 4 + slack   (slack 0: input layer / constrain 5, 1: hidden / 6)
-// (mask_constrain_cuda.cu:64-88; entropy_conv_cuda_v2.cu:326-380 evaluates the same rule as a channel limit
-// per tap) -- on average HALF of the 25 x cin entries.  Until round 3 every kernel multiplied the masked half
-// by zeros.  Now only the usable entries are enumerated, by window anti-diagonal d = kh + kw, then kh, then ci:
-//     e = 0;  for d in 0..8:  U = clamp(T - d, 0, ngroup) * group_in
-//               for kh in max(0, d-4) .. min(4, d):  for ci in 0..U-1:  entry e++ = (kh, d - kh, ci)
-// lane e % 64 of a wave accumulates its entries in ascending e with fmaf from 0, then the xor butterfly
-// 32..1, then + bias, PReLU, + residual.  This order is part of the bitstream contract: the step kernel, the
-// bulk (encoder) kernel, the per-op kernel (entropy.hip) and the oracle (orc_entropy_conv, order 2) restate it.
-// A group needs ceil(L / 64) rounds instead of ceil(25 cin / 64): 2 .. 16 instead of 17 for the hidden layers.
+// Packed weights: for every (set, output group) one slab [slot][4] holding the GO = 3
+// rows of the group interleaved (4th float is padding), slot = tap*cin + ci, padded to
+// whole waves, with the causal mask of the output group already applied (see
+// ee_kernels.h).  A lane fetches its three weights of a tap with one 16-byte LDS read and
+// a masked tap contributes fmaf(x, 0, acc) == acc (x is finite).
 __host__ __device__ constexpr int slab_slots(int cin) { return (cin * KK + kWave - 1) / kWave * kWave; }
 __host__ __device__ constexpr int slab_floats(int cin) { return slab_slots(cin) * 4; }
 
-// number of usable entries of a group with threshold T
-__host__ __device__ inline int compact_len(int T, int ngroup, int gin) {
-  int L = 0;
-  for (int d = 0; d <= 2 * (K - 1); d++) {
-    int ug = T - d;
-    ug = ug > ngroup ? ngroup : ug;
-    if (ug <= 0) break;
-    L += (d < K ? d + 1 : 2 * K - 1 - d) * ug * gin;
-  }
-  return L;
-}
-
-// Packed weights: for every (set, output group) one slab [slot e][4] in the compact order of the group:
-// {w of the group's 3 outputs, info}, info = kh << 16 | (kw * cin + ci) (as int bits): where the entry sits
-// in a window.  Slots past the group's L are {0, 0, 0, 0}: they multiply entry (0, 0, 0) by zero.
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ packed, int cin, int ngroup,
                                    int slack, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int red = cin * KK, slots = (red + kWave - 1) / kWave * kWave;
-  const int o = i & 3, grp = (i >> 2) / slots;  // grp = set*ngroup + tc
-  int rem = (i >> 2) % slots;
-  const int tc = grp % ngroup, gin = cin / ngroup, T = tc + 2 * HALF + slack;
-  int kh = 0, kw = 0, ci = 0;
-  bool live = false;
-  for (int d = 0; d <= 2 * (K - 1) && !live; d++) {
-    int ug = T - d;
-    ug = ug > ngroup ? ngroup : ug;
-    if (ug <= 0) break;
-    const int U = ug * gin, kh0 = d < K ? 0 : d - (K - 1), ntap = d < K ? d + 1 : 2 * K - 1 - d;
-    if (rem < ntap * U) {
-      kh = kh0 + rem / U;
-      ci = rem % U;
-      kw = d - kh;
-      live = true;
-    } else {
-      rem -= ntap * U;
-    }
-  }
-  float v;
-  if (o < GO)
-    v = live ? w[((size_t)grp * GO + o) * red + ci * KK + kh * K + kw] : 0.f;
-  else
-    v = __int_as_float(live ? (kh << 16) | (kw * cin + ci) : 0);
-  packed[i] = v;
+  const int o = i & 3, kk = (i >> 2) % slots, grp = (i >> 2) / slots;  // grp = set*ngroup + tc
+  const int tc = grp % ngroup, group_in = cin / ngroup;
+  const int tap = kk / cin, ci = kk - tap * cin;
+  const int kh = tap / K, kw = tap - kh * K;
+  // causality: input group gi at window offset (kh, kw) is usable iff gi + kh + kw - 4 < tc + slack
+  const bool ok = kk < red && o < GO && (2 * HALF - kh - kw) * group_in - ci + (tc + slack) * group_in > 0;
+  packed[i] = ok ? w[((size_t)grp * GO + o) * red + ci * KK + tap] : 0.f;
 }
+
+// Walks the reduction index kk = lane, lane + 64, ... and keeps its decomposition
+// kk = (kh*5 + kw)*CIN + ci up to date with a few adds (no division, no table):
+// one wave-level VALU op is much cheaper here than one more vector memory
+// instruction -- the step kernels are bound by the number of those.
+template <int CIN>
+struct TapWalk {
+  int ci, kh, kw;
+  __device__ __forceinline__ explicit TapWalk(int lane) {
+    ci = lane % CIN;
+    const int tap = lane / CIN;
+    kw = tap % K;
+    kh = tap / K;
+  }
+  __device__ __forceinline__ void next() {
+    constexpr int Q = kWave / CIN, R = kWave % CIN;
+    ci += R;
+    int inc = Q;
+    if (ci >= CIN) {
+      ci -= CIN;
+      inc++;
+    }
+    kw += inc;
+#pragma unroll
+    for (int k = 0; k < (Q + 1 + K - 1) / K; k++)
+      if (kw >= K) {
+        kw -= K;
+        kh++;
+      }
+  }
+  // element offset of the tap from the window origin / causal limit
+  __device__ __forceinline__ int off(int win) const { return (kh * win + kw) * CIN + ci; }
+  __device__ __forceinline__ int lim(int group_in) const { return (2 * HALF - kh - kw) * group_in - ci; }
+};
 
 // ---- halos ---------------------------------------------------------------
 
@@ -211,300 +250,394 @@ __global__ void ee_halo_bulk_kernel(EeGeom g, float *__restrict__ buf, int C, lo
 }
 
 // ---- layers --------------------------------------------------------------
-//
-// One kernel body for the decoder's step and the encoder's bulk pass ("band kernel", round 4).
-//
-// Geometry.  Plane ps of the wavefront crosses latitude tile t in the positions (th, tw = P - th), P = ps - t*h:
-// an anti-diagonal.  The 5 x 5 windows of NB consecutive rows of that diagonal lie in a BAND of NB + 4 rows
-// x 9 columns of the (padded) tile, and band column kh + kw is exactly the window anti-diagonal d of the
-// causal rule.  A workgroup = NPL waves takes NB rows of NPL consecutive planes of one tile of one (set,
-// image): their bands overlap, shifted by one column per plane, so the union -- (NB + 4) rows x (8 + NPL)
-// columns x C channels, every row a contiguous run of the channels-last buffer -- is staged ONCE in LDS with
-// 16-byte LDS-DMA (coalesced kilobyte pieces instead of 64-lane 4-byte gathers per window: the step kernel
-// of rounds 1-3 pulled every window out of L2 separately, 17 gathers per position, and was bound by them).
-// Window entry (kh, kw, ci) of the position in band row p of plane k sits at
-//     band[(p + kh) * S + (kh + kw + k) * C + ci] = p * S + k * C + [kh * (S + C) + kw * C + ci]:
-// a position- and plane-independent offset per entry, packed with the weights (`info`).
-//
-// Wave k owns plane k: output group tc = psum - plane.  Its weights -- the group's slab in causal-compact
-// order, only ceil(L / 64) rounds of it -- go to REGISTERS once and serve all NB positions; per position and
-// round a lane issues one ds_read_b32 (base + immediate) and three fmaf.  Eight positions share a pass
-// (24 accumulators), their 24 sums leave through two packed butterflies.
-//   step (decoder):  grid (tiles x row chunks, plane chunks of the step's window, 3 sets x images); weights
-//                    straight from global memory (every wave another group); epilogue writes the value, its
-//                    circular-wrap copy and the halo entries interpolated from it.
-//   bulk (encoder):  all planes; a wave walks ALL groups of its plane's positions, the group's slab staged in
-//                    LDS for the workgroup (double buffered, one barrier per group); halos by ee_halo_bulk.
-// Same device functions, same per-output operations in the same order: encoder and decoder tables agree bit
-// for bit, and both equal the per-op kernel and the oracle (order 2).
-template <int CIN, int NPL_, int NB_, bool BULK_>
-struct Band {
-  static constexpr int C = CIN, NPL = NPL_, NB = NB_;
-  static constexpr bool BULK = BULK_;
-  static constexpr int PB = 8;                      // positions per accumulation pass
-  static constexpr int NPASS = NB / PB;
-  static constexpr int ND = 8 + NPL;                // band columns
-  static constexpr int RL = ND * C;                 // floats of a band row
-  static constexpr int S = (RL + 3) / 4 * 4;        // row stride: rows start on 16-byte boundaries
-  static constexpr int NBR = NB + 2 * PAD;          // band rows
-  static constexpr int A = S + C;                   // address step of kh
-  static constexpr int ITER = slab_slots(CIN) / kWave;
-  static constexpr int NCH = (ITER + 19) / 20;      // weight rounds kept in registers at a time: <= 20
-  static constexpr int WCH = (ITER + NCH - 1) / NCH;
-  static constexpr int BLOCK = NPL * kWave;
-  static constexpr int PIECES = (RL + 255) / 256;   // 16-byte DMA instructions per band row
-  static constexpr int BAND_FLOATS = NBR * S;
-  // bulk: the group's slab staged in LDS for the workgroup (where two of them fit beside the band: cin <= 48;
-  // the wide models' waves fetch their rounds from global memory as the step kernel does)
-  static constexpr bool SLAB = BULK && CIN <= 48;
-  static constexpr int SLAB_FLOATS = SLAB ? 2 * ITER * kWave * 4 : 0;
-  static constexpr int TAB_FLOATS = 2 * GO * CIN;   // bias / slope of a set (cout = 3 ngroup <= 3 CIN)
-  static constexpr size_t LDS_BYTES = (size_t)(BAND_FLOATS + SLAB_FLOATS + TAB_FLOATS) * 4;
-  static_assert(NB % PB == 0 && RL % 4 == 0, "band geometry");
-  static_assert((PB - 1 + (NPASS - 1) * PB) * S * 4 + NPL * C * 4 + (4 * A + 4 * C + C) * 4 < (1 << 20), "LDS offsets");
-};
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
-// what the epilogue needs to know about the launch
-struct BandOut {
-  const float *bias_tab, *slope_tab;  // LDS: the set's bias / slope (slope 1 where the layer has none)
-  const float *rimg;                  // residual image (layout of y) or null
-  float *yimg;
-  int pad_out, cout, h, w, tile, width, has_slope;
-};
-
-// 8 positions x 3 outputs: acc[p][o] += sum over the wave's rounds of x(entry, position p) * w(entry, o).
-// xa[i]: LDS byte address of the lane's entry of round i for position 0 of the pass; position p is
-// p * S floats further (an immediate).  n: rounds (uniform).
-template <class B>
-__device__ __forceinline__ void band_rounds(float (&acc)[B::PB][GO], const float4 (&wv)[B::WCH], const unsigned (&xa)[B::WCH],
-                                            int n) {
-  typedef const __attribute__((address_space(3))) float lds_float_t;
-#pragma unroll
-  for (int i = 0; i < B::WCH; i++) {
-    if (i < n) {  // (uniform)
-      float x[B::PB];
-#pragma unroll
-      for (int p = 0; p < B::PB; p++) x[p] = *(lds_float_t *)(uintptr_t)(xa[i] + (unsigned)(p * B::S * 4));
-#pragma unroll
-      for (int p = 0; p < B::PB; p++) {
-        acc[p][0] = fmaf(x[p], wv[i].x, acc[p][0]);
-        acc[p][1] = fmaf(x[p], wv[i].y, acc[p][1]);
-        acc[p][2] = fmaf(x[p], wv[i].z, acc[p][2]);
-      }
-    }
-  }
+// copies a (pre-masked, padded) slab to LDS
+template <int CIN, int BLOCK>
+__device__ __forceinline__ void stage_weights(float *wl, const float *__restrict__ wrow, int tid) {
+  constexpr int N4 = slab_floats(CIN) / 4;
+  const float4 *src = reinterpret_cast<const float4 *>(wrow);
+  float4 *dst = reinterpret_cast<float4 *>(wl);
+  for (int i = tid; i < N4; i += BLOCK) dst[i] = src[i];
 }
 
-// info of a packed entry -> LDS byte address of the entry for band row `row0`, plane k
-template <class B>
-__device__ __forceinline__ unsigned band_entry_addr(float info, unsigned band_base, int k, int row0) {
-  const unsigned u = (unsigned)__float_as_int(info);
-  return band_base + 4u * ((u >> 16) * (unsigned)B::A + (u & 0xffffu) + (unsigned)(k * B::C + row0 * B::S));
-}
-
-// Way out of one pass: totals of 8 positions x 3 outputs (two packed butterflies), bias, PReLU, residual,
-// store; STEP: + circular-wrap copy and the halo entries interpolated from the value (see halo_write).
-// Lane L finishes position (L >> 4) (+ 4 for the second butterfly), output {0, 2, 1, 2}[(L >> 2) & 3]; the four
-// lanes of a quad hold the same total and share the value's halo records.
-template <class B>
-__device__ __forceinline__ void band_wayout(const EeGeom &g, float (&acc)[B::PB][GO], const BandOut &o, int tc, int P,
-                                            int th0, int lane) {
-  const int quad = (lane >> 2) & 3;
-  const int out = quad == 0 ? 0 : (quad == 2 ? 1 : 2);
-  const int ch = tc * GO + out;
-  const float bv = o.bias_tab[ch], sv = o.slope_tab[ch];
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const float a4[4][GO] = {{acc[4 * half][0], acc[4 * half][1], acc[4 * half][2]},
-                             {acc[4 * half + 1][0], acc[4 * half + 1][1], acc[4 * half + 1][2]},
-                             {acc[4 * half + 2][0], acc[4 * half + 2][1], acc[4 * half + 2][2]},
-                             {acc[4 * half + 3][0], acc[4 * half + 3][1], acc[4 * half + 3][2]}};
-    const float tot = butterfly12(a4, lane);
-    const int th = th0 + 4 * half + (lane >> 4);
-    const int tw = P - th;
-    if (quad == 3 || th >= o.h || tw < 0 || tw >= o.width) continue;  // no such position / duplicate of output 2
-    const size_t pix = o.pad_out ? ((size_t)o.tile * (o.h + 2 * PAD) + th + PAD) * (o.w + 2 * PAD) + tw + PAD
-                                 : ((size_t)o.tile * o.h + th) * o.w + tw;
-    float v = tot + bv;
-    if (v < 0) v = v * sv;
-    if (o.rimg) v = v + o.rimg[pix * o.cout + ch];
-    const bool writer = (lane & 3) == 0;
-    if (writer) o.yimg[pix * o.cout + ch] = v;
-    if (!B::BULK && o.pad_out) {
-      if (tw < PAD && writer) o.yimg[(pix + o.width) * o.cout + ch] = v;  // circular wrap copy
-      if (th < PAD || th >= o.h - PAD) {
-        const int rev = g.pix_rev[((size_t)o.tile * o.h + th) * o.w + tw];
-        const int nrev = rev & 15;
-        const EeHalo *hr = g.halo + (rev >> 4);
-        for (int k = lane & 3; k < nrev; k += 4) {
-          const EeHalo q = hr[k];
-          const float other = (q.info & (1 << 29)) ? v : (q.other >= 0 ? o.yimg[(size_t)q.other * o.cout + ch] : 0.f);
-          const float a = (q.info & (1 << 30)) ? other : v, b = (q.info & (1 << 30)) ? v : other;
-          const float hv = a * q.t + b * (1 - q.t);
-          float *dst = o.yimg + (size_t)q.dst * o.cout + ch;
-          *dst = hv;
-          const int wd = q.info & 0xffff;
-          if (wd) dst[(size_t)wd * o.cout] = hv;  // circular wrap of the first columns
-        }
-      }
-    }
-  }
-}
-
-template <int CIN, int NPL, int NB, bool BULK>
-__global__ __launch_bounds__(NPL * kWave) void ee_band_kernel(EeGeom g, const float *__restrict__ x, int shared_input,
-                                                              const float *__restrict__ wp,
-                                                              const float *__restrict__ bias,
-                                                              const float *__restrict__ slope,
-                                                              const float *__restrict__ residual, float *__restrict__ y,
-                                                              int pad_out, int slack, int first_plane, int nplane,
-                                                              int psum) {
-  typedef Band<CIN, NPL, NB, BULK> B;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *band = lds;
-  float *slab = lds + B::BAND_FLOATS;                     // bulk: two group slabs
-  float *tab = lds + B::BAND_FLOATS + B::SLAB_FLOATS;      // bias [cout], slope [cout]
-  const int h = g.h, w = g.w, win = w + 2 * PAD;
-  const int cout = GO * g.ngroup, gin = CIN / g.ngroup;
-  const int row_chunks = (h + NB - 1) / NB;
-  const int tile = blockIdx.x / row_chunks;
-  const int th_lo = (blockIdx.x - tile * row_chunks) * NB;
-  const int plane0 = first_plane + blockIdx.y * NPL;       // plane of wave 0
-  const int pn = blockIdx.z;                               // replica-major image index: set * nimg + img
+// Step form: grid = (parts, planes of the step's window, 3 weight sets x images).  All
+// positions of a plane share the output group, so the workgroup stages the (set, group)
+// slab ONCE, by LDS-DMA (no staging registers, no VALU); a lane keeps the byte offsets
+// of its ITER taps inside a window in registers (a table: they depend on the layer type
+// only) and the waves then walk the plane's position list with stride parts*waves.  Per
+// position: one 16-byte scalar load of its record (the next one is requested before the
+// current one is used), ITER gathers from one scalar base, 3*ITER fmaf against the LDS
+// slab, the packed butterfly, the epilogue.  The launch is a chain of memory round trips
+// per wave, so what matters is how many waves are resident (<= 64 registers: 8 per SIMD)
+// and how few dependent hops a position takes: no integer division anywhere (3-D grid,
+// precomputed records), halo entries written from 16-byte records (2 hops instead of 4).
+template <int CIN, int ITER, int BLOCK, int PJ>
+__global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (ITER * PJ <= 40 ? (PJ > 1 ? 6 : 4) : 2))) void ee_step_kernel(
+    EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
+    const uint32_t *__restrict__ tapoff, const float *__restrict__ bias, const float *__restrict__ slope,
+    const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum,
+    int contiguous) {
+  constexpr int kWaves = BLOCK / kWave;
+  constexpr int SLOTS = ITER * kWave;
+  static_assert(SLOTS == slab_slots(CIN), "ITER must cover the padded reduction length");
+  const int part = blockIdx.x, split = gridDim.x;
+  const int plane = first_plane + blockIdx.y;
+  const int pn = blockIdx.z;  // replica-major image index: set * nimg + img
   const int set = (pn >= g.nimg) + (pn >= 2 * g.nimg);
+  const int img = pn - set * g.nimg;
+  typedef const __attribute__((address_space(4))) int32_t const_i32_t;
+  const_i32_t *pstart = (const_i32_t *)g.plane_start;
+  const int lo = pstart[plane];
+  const int cnt = pstart[plane + 1] - lo;
+  // A workgroup takes a CONTIGUOUS share of the plane's position list (neighbours on the
+  // anti-diagonal: their 5 x 5 windows overlap, 16 of 25 taps between direct neighbours, so what
+  // one wave gathered the next finds in the CU's L1) -- the kernel is bound by the bytes its
+  // gathers pull out of L2.  contiguous = 0: the interleaved assignment (position e of a wave,
+  // e + waves*parts the next one).
+  const int share = contiguous ? (cnt + split - 1) / split : cnt;
+  const int first = contiguous ? part * share : part * kWaves;
+  const int last = contiguous ? (first + share < cnt ? first + share : cnt) : cnt;
+  if (first >= cnt) return;  // uniform for the workgroup
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int width = g.widths[tile];
-  const int nrows = h - th_lo < NB ? h - th_lo : NB;
-  const int P0 = plane0 - tile * h;                        // column of wave 0's diagonal in row 0 of the tile
-  // does any position (th_lo + p, P0 + k - th_lo - p), p < nrows, k < planes here, exist?
-  const int nplanes_here = first_plane + nplane - plane0 < NPL ? first_plane + nplane - plane0 : NPL;
-  if (nplanes_here <= 0 || P0 + nplanes_here - 1 - th_lo < 0 || P0 - th_lo - (nrows - 1) >= width) return;  // (uniform)
-
-  // ---- stage the band: rows th_lo .. th_lo + nrows + 3 (padded coordinates) of the tile, row b from padded
-  // column P0 - th_lo - b on, ND columns.  A row is one contiguous run of the channels-last buffer (it may
-  // start left of the tile row or end right of it: those bytes belong to columns no existing position reads,
-  // and the engine allocates its buffers with a guard band so that the addresses are valid).
-  const size_t in_img = (size_t)g.npart * (h + 2 * PAD) * win * CIN;
-  const float *ximg = x + (size_t)(shared_input ? pn - set * g.nimg : pn) * in_img;
+  const int tc = psum - plane;
+  const int cout = GO * g.ngroup;
+  const int h = g.h, w = g.w;
+  const int win = w + 2 * PAD;
+  __shared__ __attribute__((aligned(16))) float4 lw[SLOTS];
   {
-    const long long row0 = ((long long)tile * (h + 2 * PAD) + th_lo) * win + (P0 - th_lo);
-    const int nbr = nrows + 2 * PAD;
-    for (int b = wave; b < nbr; b += NPL) {
-      const float *src = ximg + (row0 + (long long)b * (win - 1)) * CIN;
-#pragma unroll
-      for (int j = 0; j < B::PIECES; j++) {
-        const int f = (j * kWave + lane) * 4;
-        if (f < B::RL)
-          __builtin_amdgcn_global_load_lds((glb_void_t *)(src + f), (lds_void_t *)(band + b * B::S + j * 256), 16, 0, 0);
-      }
-    }
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    const float4 *slab = reinterpret_cast<const float4 *>(wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN));
+    for (int i = wave; i < ITER; i += kWaves)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(slab + i * kWave + lane), (lds_ptr_t *)(lw + i * kWave), 16, 0, 0);
   }
-  // bias / slope of the set
-  for (int i = threadIdx.x; i < cout; i += B::BLOCK) {
-    tab[i] = bias[set * cout + i];
-    tab[cout + i] = slope ? slope[set * cout + i] : 1.f;  // (v * 1 is v)
-  }
-  const int plane = plane0 + wave;
-  const bool plane_ok = wave < nplanes_here;
-  const int P = P0 + wave;
-  // rows of this wave's diagonal that exist: th in [th_lo, th_lo + nrows), 0 <= P - th < width
-  const bool wave_live = plane_ok && P - th_lo >= 0 && P - th_lo - (nrows - 1) < width;
-  const size_t out_img = (size_t)g.npart * (h + 2 * pad_out) * (w + 2 * pad_out) * cout;
-  BandOut out = {tab, tab + cout, residual ? residual + (size_t)pn * out_img : nullptr, y + (size_t)pn * out_img,
-                 pad_out, cout, h, w, tile, width, slope != nullptr};
-  const unsigned band_base = (unsigned)(uintptr_t)band;  // low half of the flat address = LDS byte offset
-  const float4 *wset = reinterpret_cast<const float4 *>(wp) + (size_t)set * g.ngroup * (B::ITER * kWave);
-
-  if constexpr (!BULK) {
-    const int tc = psum - plane;
-    const int L = compact_len(tc + 2 * HALF + slack, g.ngroup, gin);
-    const int niter = wave_live ? (L + kWave - 1) / kWave : 0;
-    const float4 *wg = wset + (size_t)(wave_live ? tc : 0) * (B::ITER * kWave) + lane;
-    float4 wv[B::WCH];
-    unsigned xa[B::WCH];
-    // the first (for cin <= 48: the only) chunk of weight rounds is requested before the band has landed
-#pragma unroll
-    for (int i = 0; i < B::WCH; i++)
-      if (i < niter) wv[i] = wg[i * kWave];
-    __syncthreads();  // band and table are in LDS (the barrier waits for vmcnt(0): the DMA)
-    if (!wave_live) return;
-#pragma unroll 1
-    for (int pass = 0; pass < B::NPASS; pass++) {
-      const int th0 = th_lo + pass * B::PB;
-      if (pass * B::PB >= nrows || P - th0 < 0 || P - th0 - (B::PB - 1) >= width) continue;  // (uniform) nothing in this pass
-      float acc[B::PB][GO];
-#pragma unroll
-      for (int p = 0; p < B::PB; p++) acc[p][0] = acc[p][1] = acc[p][2] = 0.f;
-#pragma unroll 1
-      for (int c = 0; c < B::NCH; c++) {
-        const int n = niter - c * B::WCH < B::WCH ? niter - c * B::WCH : B::WCH;
-        if (n <= 0) break;
-        if (c > 0 || pass > 0) {
-#pragma unroll
-          for (int i = 0; i < B::WCH; i++)
-            if (i < n) wv[i] = wg[(c * B::WCH + i) * kWave];
-        }
-#pragma unroll
-        for (int i = 0; i < B::WCH; i++)
-          if (i < n) xa[i] = band_entry_addr<B>(wv[i].w, band_base, wave, pass * B::PB);
-        band_rounds<B>(acc, wv, xa, n);
-      }
-      band_wayout<B>(g, acc, out, tc, P, th0, lane);
-    }
+  // byte offsets of a lane's ITER taps inside a window: unsigned 32-bit, so the gathers are "scalar
+  // base + lane offset" loads.  One position at a time they live in registers; with PJ > 1 the
+  // registers go to the second window and the table sits in LDS (read once per PJ positions)
+  unsigned off[PJ > 1 ? 1 : ITER];
+  __shared__ unsigned toff[PJ > 1 ? SLOTS : 1];
+  if (PJ > 1) {
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    for (int i = wave; i < ITER; i += kWaves)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(tapoff + i * kWave + lane), (lds_ptr_t *)(toff + i * kWave), 4, 0, 0);
   } else {
-    // bulk: every group of the plane's positions.  SLAB: the group's slab (only its ceil(L / 64) rounds) is
-    // staged for the workgroup by LDS-DMA, double buffered: slab tc + 1 lands while group tc is computed.
-    auto stage_slab = [&](int tc) {
-      if constexpr (B::SLAB) {
-        const int L = compact_len(tc + 2 * HALF + slack, g.ngroup, gin);
-        const int n = (L + kWave - 1) / kWave;
-        const float4 *src = wset + (size_t)tc * (B::ITER * kWave) + lane;
-        float *dst = slab + (tc & 1) * (B::ITER * kWave * 4);
-        for (int i = wave; i < n; i += NPL)
-          __builtin_amdgcn_global_load_lds((glb_void_t *)(src + i * kWave), (lds_void_t *)(dst + i * kWave * 4), 16, 0, 0);
-      }
-    };
-    stage_slab(0);
-    if constexpr (!B::SLAB) __syncthreads();  // band and table
-#pragma unroll 1
-    for (int tc = 0; tc < g.ngroup; tc++) {
-      if constexpr (B::SLAB) {
-        __syncthreads();  // slab tc (and, the first time, band and table) landed; everybody is done with slab tc - 1
-        if (tc + 1 < g.ngroup) stage_slab(tc + 1);
-      }
-      if (!wave_live) continue;
-      const int L = compact_len(tc + 2 * HALF + slack, g.ngroup, gin);
-      const int niter = (L + kWave - 1) / kWave;
-      const float4 *wg = wset + (size_t)tc * (B::ITER * kWave) + lane;
-      const float4 *ws = reinterpret_cast<const float4 *>(slab + (tc & 1) * (B::ITER * kWave * 4)) + lane;
-#pragma unroll 1
-      for (int pass = 0; pass < B::NPASS; pass++) {
-        const int th0 = th_lo + pass * B::PB;
-        if (pass * B::PB >= nrows || P - th0 < 0 || P - th0 - (B::PB - 1) >= width) continue;
-        float acc[B::PB][GO];
 #pragma unroll
-        for (int p = 0; p < B::PB; p++) acc[p][0] = acc[p][1] = acc[p][2] = 0.f;
+    for (int it = 0; it < ITER; it++) off[it] = tapoff[it * kWave + lane];
+  }
+  const int pout0 = tc * GO;
+  const int bidx = set * cout + pout0;
+  const float b0 = bias[bidx], b1 = bias[bidx + 1], b2 = bias[bidx + 2];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (slope) {
+    s0 = slope[bidx];
+    s1 = slope[bidx + 1];
+    s2 = slope[bidx + 2];
+  }
+  const size_t in_img = (size_t)g.npart * (h + 2 * PAD) * win * CIN;
+  const size_t out_img = (size_t)g.npart * (h + 2 * pad_out) * (w + 2 * pad_out) * cout;
+  const float *ximg = x + (size_t)(shared_input ? img : pn) * in_img;
+  float *yimg = y + (size_t)pn * out_img;
+  const float *rimg = residual ? residual + (size_t)pn * out_img : nullptr;
+  __syncthreads();  // (waits for the DMA: vmcnt(0))
+  int e = first + wave;
+  if (e >= last) return;
+  const int stride = contiguous ? kWaves : split * kWaves;
+  // read-only table, wave-uniform index: through the constant address space these are
+  // scalar loads (s_load_dwordx4), not a vector load + readfirstlane
+  const_i32_t *plist = (const_i32_t *)(g.pos + lo);
+  auto load_pos = [&](int i) {
+    EePos p;
+    p.pix = plist[4 * i];
+    p.hw = plist[4 * i + 1];
+    p.wrap = plist[4 * i + 2];
+    p.rev = plist[4 * i + 3];
+    return p;
+  };
+  // PJ positions (e, e + stride, ...) go through the loop body together: their gathers are in
+  // flight at the same time, ONE pass over the LDS slab feeds all their fmaf chains (the slab reads
+  // were as many LDS cycles as the fmafs were VALU cycles), and a wave's chain of dependent round
+  // trips is PJ times shorter.  Per position the operations and their order are unchanged.
+  EePos rec[PJ];
+#pragma unroll
+  for (int j = 0; j < PJ; j++) rec[j] = load_pos(e + j * stride < last ? e + j * stride : e);
 #pragma unroll 1
-        for (int c = 0; c < B::NCH; c++) {
-          const int n = niter - c * B::WCH < B::WCH ? niter - c * B::WCH : B::WCH;
-          if (n <= 0) break;
-          float4 wv[B::WCH];
-          unsigned xa[B::WCH];
+  for (;;) {
+    const int en = e + PJ * stride;
+    EePos nxt[PJ];  // requested now, used by the next iteration
 #pragma unroll
-          for (int i = 0; i < B::WCH; i++)
-            if (i < n) wv[i] = B::SLAB ? ws[(c * B::WCH + i) * kWave] : wg[(c * B::WCH + i) * kWave];
+    for (int j = 0; j < PJ; j++) nxt[j] = load_pos(en + j * stride < last ? en + j * stride : e);
+    float xv[PJ][ITER];
+    size_t oflat[PJ];
+    float r0[PJ], r1[PJ], r2[PJ];  // issued with the gathers: one memory round trip per position
+    const float *xin[PJ];
 #pragma unroll
-          for (int i = 0; i < B::WCH; i++)
-            if (i < n) xa[i] = band_entry_addr<B>(wv[i].w, band_base, wave, pass * B::PB);
-          band_rounds<B>(acc, wv, xa, n);
-        }
-        band_wayout<B>(g, acc, out, tc, P, th0, lane);
+    for (int j = 0; j < PJ; j++) {
+      xin[j] = ximg + (size_t)rec[j].pix * CIN;  // window origin (row-2, col-2) in padded coordinates
+      oflat[j] = (size_t)(pad_out ? rec[j].pix + 2 * win + 2 : rec[j].hw) * cout + pout0;
+    }
+    int tl = lane;  // (opaque: the table reads below must not be hoisted out of the position loop into registers)
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+      // (opaque to the optimiser: a zero-extension hoisted out of the loop would
+      // turn every gather into a 64-bit VALU add + a 2-register address)
+      unsigned o = PJ > 1 ? toff[tl + it * kWave] : off[PJ > 1 ? 0 : it];
+      asm volatile("" : "+v"(o));
+#pragma unroll
+      for (int j = 0; j < PJ; j++)
+        xv[j][it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin[j]) + o);
+    }
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      r0[j] = r1[j] = r2[j] = 0.f;
+      if (rimg) {
+        r0[j] = rimg[oflat[j]];
+        r1[j] = rimg[oflat[j] + 1];
+        r2[j] = rimg[oflat[j] + 2];
       }
     }
+    float a0[PJ], a1[PJ], a2[PJ];
+    if constexpr (PJ == 2) {
+      // the two positions' chains as packed fp32 FMAs (v_pk_fma_f32: two IEEE fmas per instruction,
+      // the same bits as two v_fma_f32)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const float4 wv = lw[lane + it * kWave];
+        asm volatile("" ::"v"(wv.w));  // (see below)
+        const f2 xx = {xv[0][it], xv[1][it]};
+        p0 = __builtin_elementwise_fma(xx, (f2){wv.x, wv.x}, p0);
+        p1 = __builtin_elementwise_fma(xx, (f2){wv.y, wv.y}, p1);
+        p2 = __builtin_elementwise_fma(xx, (f2){wv.z, wv.z}, p2);
+        if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      a0[0] = p0.x, a0[1] = p0.y, a1[0] = p1.x, a1[1] = p1.y, a2[0] = p2.x, a2[1] = p2.y;
+    } else {
+#pragma unroll
+      for (int j = 0; j < PJ; j++) a0[j] = a1[j] = a2[j] = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const float4 wv = lw[lane + it * kWave];
+        // (the padding float kept live: a 16-byte ds_read_b128 takes 4 LDS cycles, the
+        // 12-byte ds_read_b96 the compiler would otherwise pick takes 8)
+        asm volatile("" ::"v"(wv.w));
+#pragma unroll
+        for (int j = 0; j < PJ; j++) {
+          a0[j] = fmaf(xv[j][it], wv.x, a0[j]);
+          a1[j] = fmaf(xv[j][it], wv.y, a1[j]);
+          a2[j] = fmaf(xv[j][it], wv.z, a2[j]);
+        }
+      }
+    }
+    // one packed butterfly per position; the row of 16 lanes a lane sits in decides which output
+    // it finishes (rows 0 / 2 / 1,3 -> outputs 0 / 1 / 2), and the epilogue is spread the same way
+    const int row = lane >> 4;
+    const int o = row == 0 ? 0 : (row == 2 ? 1 : 2);
+    const bool writer = (lane & 15) == 0 && row != 3;  // one lane per output
+    float vsum[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      vsum[j] = butterfly3(a0[j], a1[j], a2[j]);
+      // (opaque: otherwise the whole chain of a position that may not exist -- gathers, slab reads,
+      // fmafs -- is sunk into the branch that stores it, and the positions run one after the other)
+      asm volatile("" : "+v"(vsum[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < PJ; j++) {
+      if (j > 0 && e + j * stride >= last) break;  // (uniform) no such position: its lanes computed a copy of e
+      float v = vsum[j] + (o == 0 ? b0 : (o == 1 ? b1 : b2));
+      if (slope) {
+        const float sl = o == 0 ? s0 : (o == 1 ? s1 : s2);
+        v = v < 0 ? v * sl : v;
+      }
+      if (rimg) v = v + (o == 0 ? r0[j] : (o == 1 ? r1[j] : r2[j]));
+      if (writer) yimg[oflat[j] + o] = v;
+      if (pad_out) {
+        if (rec[j].wrap && writer) yimg[oflat[j] + (size_t)rec[j].wrap * cout + o] = v;  // circular wrap copy
+        const int nrev = rec[j].rev & 15;
+        if (nrev && row != 3) {
+          // this value feeds halo rows of the neighbouring tiles: the 16 lanes of a row share
+          // the entries interpolated from it
+          const EeHalo *hr = g.halo + (rec[j].rev >> 4);
+          const int ch = pout0 + o;
+          for (int k = lane & 15; k < nrev; k += 16) {
+            const EeHalo q = hr[k];
+            const float other = (q.info & (1 << 29)) ? v : (q.other >= 0 ? yimg[(size_t)q.other * cout + ch] : 0.f);
+            const float a = (q.info & (1 << 30)) ? other : v, b = (q.info & (1 << 30)) ? v : other;
+            const float hv = a * q.t + b * (1 - q.t);
+            float *dst = yimg + (size_t)q.dst * cout + ch;
+            *dst = hv;
+            const int wd = q.info & 0xffff;
+            if (wd) dst[(size_t)wd * cout] = hv;  // circular wrap of the first columns
+          }
+        }
+      }
+    }
+    if (en >= last) break;
+#pragma unroll
+    for (int j = 0; j < PJ; j++) rec[j] = nxt[j];
+    e = en;
+  }
+}
+
+// Encoder ("bulk") form of the same layer: every symbol is known, so a position
+// can be evaluated for ALL its channel groups at once.  A wave owns PP positions:
+// it gathers their 5 x 5 x CIN windows a single time, then walks the groups -- the
+// workgroup stages the group's (pre-masked) slab in LDS, every lane reads its taps'
+// weights once (causally masked taps are zeros) and feeds the PP masked fmaf chains
+// + butterflies of its positions.  Per output the operations and their order are
+// exactly those of the step kernel above (psum = plane + group), so encoder and
+// decoder tables agree bit for bit.  Halos of the output are filled afterwards by
+// ee_halo_bulk.
+template <int CIN, int ITER, int BLOCK, int PP>
+__global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
+    EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
+    const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
+    float *__restrict__ y, int cout, int constrain, int pad_out) {
+  constexpr int RED = CIN * KK;
+  constexpr int kPosPerWg = BLOCK / kWave * PP;
+  __shared__ __attribute__((aligned(16))) float wl2[2][slab_floats(CIN)];  // double-buffered weight slab
+  const int nchunk = (g.npos + kPosPerWg - 1) / kPosPerWg;
+  const int chunk = blockIdx.x % nchunk;
+  const int pn = blockIdx.x / nchunk;  // replica-major image index, 0 .. 3*nimg
+  const int set = pn / g.nimg;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int h = g.h, w = g.w;
+  const int win = w + 2 * PAD;
+  const int tile_elems = (h + 2 * PAD) * win * CIN;
+  const int xi = shared_input ? pn % g.nimg : pn;
+  const float *ximg = x + (size_t)xi * g.npart * tile_elems;
+  const int idx0 = (chunk * (BLOCK / kWave) + wave) * PP;
+  unsigned off[ITER];  // byte offsets of this lane's taps inside a window
+  {
+    TapWalk<CIN> tw(lane);
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+      off[it] = (lane + it * kWave < RED) ? 4u * (unsigned)tw.off(win) : 0u;
+      tw.next();
+    }
+  }
+  float xv[PP][ITER];
+  size_t obase[PP];
+#pragma unroll
+  for (int j = 0; j < PP; j++) {
+    const int idx = idx0 + j < g.npos ? idx0 + j : 0;
+    const Pos p = decode_pos(__builtin_amdgcn_readfirstlane(g.order[idx]), h, w);
+    const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+      unsigned o = off[it];
+      asm volatile("" : "+v"(o));  // keeps the zero-extension out of a hoisted 64-bit add (see ee_conv_kernel)
+      const float v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin) + o);
+      // lanes past the reduction length (last iteration only) contribute fmaf(0, w, acc) == acc
+      xv[j][it] = ((it + 1) * kWave <= RED || lane + it * kWave < RED) ? v : 0.f;
+    }
+    obase[j] = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
+                p.tw + pad_out) * cout;
+  }
+  stage_weights<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x);
+  // bias and slope of the set's outputs in LDS, once: loaded per group in front of their use they sat behind the
+  // store of the group before (vmcnt counts stores too, and a guarded load is waited for with vmcnt(0)): one
+  // exposed store -> load round trip per group and wave
+  __shared__ float bs_tab[2][GO * CIN];  // (cout = 3 ngroup, ngroup = CIN or CIN / 3)
+  for (int i = threadIdx.x; i < cout; i += BLOCK) {
+    bs_tab[0][i] = bias[set * cout + i];
+    bs_tab[1][i] = slope ? slope[set * cout + i] : 1.f;  // (v * 1 is v)
+  }
+  __syncthreads();
+  for (int tc = 0; tc < g.ngroup; tc++) {
+    // the next group's slab goes to the other buffer while this one is used (its
+    // last readers passed the barrier that ended the previous iteration)
+    if (tc + 1 < g.ngroup)
+      stage_weights<CIN, BLOCK>(wl2[(tc + 1) & 1], wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN),
+                                threadIdx.x);
+    const float *wl = wl2[tc & 1];
+    float acc[PP][GO];
+    if constexpr (PP == 4) {
+      // the four positions' chains as packed fp32 FMAs, two positions per instruction (v_pk_fma_f32: two
+      // IEEE fmas, the same bits as two v_fma_f32) -- r3: the loop was 12 scalar FMAs per LDS read, VALU-bound
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 p[2][GO];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int o = 0; o < GO; o++) p[q][o] = (f2){0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const int kk = lane + it * kWave;
+        const int kc = kk < RED ? kk : RED - 1;
+        const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);  // causally masked taps are zeros
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const f2 xx = {xv[2 * q][it], xv[2 * q + 1][it]};
+          p[q][0] = __builtin_elementwise_fma(xx, (f2){wv.x, wv.x}, p[q][0]);
+          p[q][1] = __builtin_elementwise_fma(xx, (f2){wv.y, wv.y}, p[q][1]);
+          p[q][2] = __builtin_elementwise_fma(xx, (f2){wv.z, wv.z}, p[q][2]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int o = 0; o < GO; o++) {
+          acc[2 * q][o] = p[q][o].x;
+          acc[2 * q + 1][o] = p[q][o].y;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PP; j++)
+#pragma unroll
+        for (int o = 0; o < GO; o++) acc[j][o] = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const int kk = lane + it * kWave;
+        const int kc = kk < RED ? kk : RED - 1;
+        const float4 wv = *reinterpret_cast<const float4 *>(wl + 4 * kc);  // causally masked taps are zeros
+#pragma unroll
+        for (int j = 0; j < PP; j++) {
+          acc[j][0] = fmaf(xv[j][it], wv.x, acc[j][0]);
+          acc[j][1] = fmaf(xv[j][it], wv.y, acc[j][1]);
+          acc[j][2] = fmaf(xv[j][it], wv.z, acc[j][2]);
+        }
+      }
+    }
+    if constexpr (PP == 4) {
+      // all 12 reductions at once; lane L ends with position L >> 4, output {0,2,1,2}[quad]
+      const float tot = butterfly12(acc, lane);
+      const int j = lane >> 4, quad = (lane >> 2) & 3;
+      const int o = quad == 0 ? 0 : (quad == 2 ? 1 : 2);
+      if ((lane & 3) == 0 && quad != 3 && idx0 + j < g.npos) {
+        const int pout = tc * GO + o;
+        const size_t ob = j == 0 ? obase[0] : (j == 1 ? obase[1] : (j == 2 ? obase[2] : obase[3]));
+        float v = tot + bs_tab[0][pout];
+        if (v < 0) v = v * bs_tab[1][pout];
+        if (residual) v = v + residual[ob + pout];
+        y[ob + pout] = v;
+      }
+    } else {
+      const int pout = tc * GO + (lane < GO ? lane : 0);
+      const int bidx = set * cout + pout;
+      const float bv = bias[bidx];
+      const float sv = slope ? slope[bidx] : 0.f;
+#pragma unroll
+      for (int j = 0; j < PP; j++) {
+#pragma unroll
+        for (int o = 0; o < GO; o++) acc[j][o] = butterfly_sum(acc[j][o]);
+        if (idx0 + j < g.npos && lane < GO) {
+          float v = acc[j][0];
+#pragma unroll
+          for (int o = 1; o < GO; o++) v = (lane == o) ? acc[j][o] : v;
+          v = v + bv;
+          if (slope && v < 0) v = v * sv;
+          if (residual) v = v + residual[obase[j] + pout];
+          y[obase[j] + pout] = v;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -768,76 +901,69 @@ int ee_pack_weight(const float *w, float *packed, int nset, int cout, int cin, i
   return PCONV_OK;
 }
 
-namespace {
-
-// raises a kernel's dynamic-LDS limit once per device
-template <class Kernel>
-int band_lds_limit(Kernel kernel, size_t bytes, std::atomic<unsigned long long> &raised) {
-  if (bytes <= 48 * 1024) return PCONV_OK;
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess) device = 0;
-  const unsigned long long bit = 1ULL << (device & 63);
-  if (raised.load(std::memory_order_acquire) & bit) return PCONV_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)bytes);
-  if (e != hipSuccess) {
-    pconv_set_error("ee_conv: cannot raise dynamic LDS to %zu: %s", bytes, hipGetErrorString(e));
-    return PCONV_ELAUNCH;
-  }
-  raised.fetch_or(bit, std::memory_order_release);
-  return PCONV_OK;
-}
-
-template <int CIN, int NPL, int NB, bool BULK>
-int band_launch(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
-                const float *slope, const float *residual, float *y, int pad_out, int slack, int first_plane,
-                int nplane, int psum, void *stream) {
-  typedef Band<CIN, NPL, NB, BULK> B;
-  static std::atomic<unsigned long long> raised{0};
-  auto kernel = ee_band_kernel<CIN, NPL, NB, BULK>;
-  static_assert(B::LDS_BYTES <= 160 * 1024, "band + slabs fit the LDS of a CU");
-  if (int rc = band_lds_limit(kernel, B::LDS_BYTES, raised)) return rc;
-  const dim3 grid((unsigned)(g->npart * ((g->h + NB - 1) / NB)), (unsigned)((nplane + NPL - 1) / NPL),
-                  (unsigned)(3 * g->nimg));
-  PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images / planes for one launch");
-  hipLaunchKernelGGL(kernel, grid, dim3(B::BLOCK), B::LDS_BYTES, as_stream(stream), *g, x, shared_input, packed_w, bias,
-                     slope, residual, y, pad_out, slack, first_plane, nplane, psum);
-  return PCONV_OK;
-}
-
-}  // namespace
-
 int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
             const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
-            int first_plane, int nplane, int psum, void *stream) {
-  if (nplane <= 0) return PCONV_OK;
+            int first_plane, int nplane, int longest_plane, int psum, void *stream) {
+  if (nplane <= 0 || longest_plane <= 0) return PCONV_OK;
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv: cout must be 3 per group");
   PCONV_REQUIRE(cin == g->ngroup || cin == 3 * g->ngroup, "ee_conv: cin must be 1 or 3 per group");
-  const int slack = constrain == 5 ? 0 : 1;  // (the causal mask is also part of the packed slab's order)
-  // PCONV_EE_ROWS: rows of a tile's diagonal per workgroup (8: more, shorter workgroups -- the step is a
-  // latency chain; 16: one band serves twice the positions)
-  static const int rows_env = getenv("PCONV_EE_ROWS") ? atoi(getenv("PCONV_EE_ROWS")) : 0;
-  const int nb = rows_env == 16 || rows_env == 8 ? rows_env : 8;
-#define EE_STEP(CIN)                                                                                             \
-  (nb == 16 ? band_launch<CIN, 4, 16, false>(g, x, shared_input, packed_w, bias, slope, residual, y, pad_out, slack, \
-                                             first_plane, nplane, psum, stream)                                  \
-            : band_launch<CIN, 4, 8, false>(g, x, shared_input, packed_w, bias, slope, residual, y, pad_out, slack,  \
-                                            first_plane, nplane, psum, stream))
-  int rc;
-  switch (cin) {
-    case 14: rc = EE_STEP(14); break;
-    case 42: rc = EE_STEP(42); break;
-    case 28: rc = EE_STEP(28); break;
-    case 84: rc = EE_STEP(84); break;
-    case 48: rc = EE_STEP(48); break;
-    case 144: rc = band_launch<144, 4, 8, false>(g, x, shared_input, packed_w, bias, slope, residual, y, pad_out, slack,
-                                                 first_plane, nplane, psum, stream); break;
-    default:
-      pconv_set_error("ee_conv: %d input channels not instantiated (14/42, 28/84, 48/144)", cin);
-      return PCONV_EINVAL;
+  (void)constrain;  // the causal mask is part of the packed slab
+  // workgroups per (set, plane, image): enough to fill the chip, few enough that a staged
+  // slab serves several positions.  PCONV_EE_BLOCK (threads per workgroup: 256 / 512 / 1024)
+  // and PCONV_EE_PPW (positions a wave walks) are tuning knobs.
+  static const int block = getenv("PCONV_EE_BLOCK") ? atoi(getenv("PCONV_EE_BLOCK")) : kConvBlock;
+  // measured (MI355X, 4096x2048, decode of 1 / 2 / 4 / 8 frames in two groups, contiguous shares, two
+  // positions per loop body): 2 positions per wave 93 / 109 / - / - ms, 4: 96 / 110 / 150 / 222,
+  // 8: 116 / 126 / 140 / 211, 16: - / 137 / 164 / 213; 512- and 1024-thread workgroups are slower
+  // at every batch size
+  static const int ppw_env = getenv("PCONV_EE_PPW") ? atoi(getenv("PCONV_EE_PPW")) : 0;
+  const int ppw = ppw_env > 0 ? ppw_env : (g->nimg <= 1 ? 2 : 2 * kPosPerWave);
+  // PCONV_EE_JOINT: positions a wave takes through the loop body together (1 or 2)
+  static const int joint = getenv("PCONV_EE_JOINT") ? atoi(getenv("PCONV_EE_JOINT")) : 2;
+  // PCONV_EE_CONTIG: contiguous (1) or interleaved (0) shares of a plane per workgroup
+  static const int contig = getenv("PCONV_EE_CONTIG") ? atoi(getenv("PCONV_EE_CONTIG")) : 1;
+  const int waves = block / kWave;
+  int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
+  if (split < 1) split = 1;
+  const uint32_t *tap = cin == g->ngroup ? g->tap_in : g->tap_hid;
+  const dim3 grid((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));
+  PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images for one launch");
+#define EE_LAUNCH_J(CIN, ITER, BLK, PJ)                                                                      \
+  hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, BLK, PJ>), grid, dim3(BLK), 0, as_stream(stream), *g, x,     \
+                     shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum, contig)
+#define EE_LAUNCH_B(CIN, ITER, BLK)                          \
+  if (joint == 2 && ITER <= 20 && ppw >= 2) {                \
+    EE_LAUNCH_J(CIN, ITER, BLK, (ITER <= 20 ? 2 : 1));       \
+  } else {                                                   \
+    EE_LAUNCH_J(CIN, ITER, BLK, 1);                          \
   }
-#undef EE_STEP
-  if (rc < 0) return rc;
+#define EE_LAUNCH(CIN, ITER)              \
+  if (block == 1024) {                    \
+    EE_LAUNCH_B(CIN, ITER, 1024);         \
+  } else if (block == 512) {              \
+    EE_LAUNCH_B(CIN, ITER, 512);          \
+  } else {                                \
+    EE_LAUNCH_B(CIN, ITER, 256);          \
+  }
+  if (cin == 14) {
+    EE_LAUNCH(14, 6);
+  } else if (cin == 42) {
+    EE_LAUNCH(42, 17);
+  } else if (cin == 28) {
+    EE_LAUNCH(28, 11);
+  } else if (cin == 84) {
+    EE_LAUNCH(84, 33);
+  } else if (cin == 48) {
+    EE_LAUNCH(48, 19);
+  } else if (cin == 144) {
+    EE_LAUNCH(144, 57);
+  } else {
+    pconv_set_error("ee_conv: %d input channels not instantiated (14/42, 28/84, 48/144)", cin);
+    return PCONV_EINVAL;
+  }
+#undef EE_LAUNCH
+#undef EE_LAUNCH_B
+#undef EE_LAUNCH_J
   PCONV_LAUNCH_CHECK("ee_conv");
   return PCONV_OK;
 }
@@ -846,24 +972,36 @@ int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float 
                  const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
                  void *stream) {
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv_bulk: cout must be 3 per group");
-  const int slack = constrain == 5 ? 0 : 1;
-  const int nplane = g->h * g->npart + g->w - 1;
-#define EE_BULK(CIN, NB) \
-  band_launch<CIN, 4, NB, true>(g, x, shared_input, packed_w, bias, slope, residual, y, pad_out, slack, 0, nplane, 0, stream)
-  int rc;
-  switch (cin) {
-    case 14: rc = EE_BULK(14, 16); break;
-    case 42: rc = EE_BULK(42, 16); break;
-    case 28: rc = EE_BULK(28, 16); break;
-    case 48: rc = EE_BULK(48, 16); break;
-    case 84: rc = EE_BULK(84, 16); break;
-    case 144: rc = EE_BULK(144, 8); break;
-    default:
-      pconv_set_error("ee_conv_bulk: %d input channels not instantiated (14/42, 28/84, 48/144)", cin);
-      return PCONV_EINVAL;
+  constexpr int kBlock = 1024;
+  // positions per wave (each staged weight slab then serves 16x as many): as many as
+  // fit 128 registers beside the window (ITER values per position)
+  const int iter = (cin * KK + kWave - 1) / kWave;
+  const int pp = iter <= 20 ? 4 : 1;
+  const long long per_wg = kBlock / kWave * pp;
+  const long long nchunk = (g->npos + per_wg - 1) / per_wg;
+  const long long grid = (long long)3 * g->nimg * nchunk;
+  PCONV_REQUIRE(grid > 0 && grid < (1LL << 31), "ee_conv_bulk: grid %lld out of range", grid);
+#define EE_BULK(CIN, ITER)                                                                                   \
+  hipLaunchKernelGGL((ee_conv_bulk_kernel<CIN, ITER, kBlock, (ITER <= 20 ? 4 : 1)>), dim3((unsigned)grid), dim3(kBlock), 0,        \
+                     as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
+                     pad_out)
+  if (cin == 14) {
+    EE_BULK(14, 6);
+  } else if (cin == 42) {
+    EE_BULK(42, 17);
+  } else if (cin == 28) {
+    EE_BULK(28, 11);
+  } else if (cin == 84) {
+    EE_BULK(84, 33);
+  } else if (cin == 48) {
+    EE_BULK(48, 19);
+  } else if (cin == 144) {
+    EE_BULK(144, 57);
+  } else {
+    pconv_set_error("ee_conv_bulk: %d input channels not instantiated (14/42, 28/84, 48/144)", cin);
+    return PCONV_EINVAL;
   }
 #undef EE_BULK
-  if (rc < 0) return rc;
   PCONV_LAUNCH_CHECK("ee_conv_bulk");
   return PCONV_OK;
 }
