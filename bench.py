@@ -45,7 +45,16 @@ import torch.distributed as dist
 VALID_FRACTION = 836.0 / 1024.0      # valid columns / all columns
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md, dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md, HBM3E
-WINOGRAD_GAIN = 2.25                 # F(2x2,3x3): 16 matrix multiply-adds per 2x2 outputs instead of 36
+WINOGRAD_GAIN = {"wino_": 2.25,      # F(2x2,3x3): 16 matrix multiply-adds per 2x2 outputs instead of 36
+                 "wino42_": 3.0}      # F(4x2,3x3): 24 per 4x2 outputs instead of 72
+
+
+def winograd_gain(kernel):
+    """direct-convolution flops per executed matrix-core flop of a tile-conv kernel (1 for the direct kernels)"""
+    for prefix, gain in WINOGRAD_GAIN.items():
+        if kernel.startswith(prefix):
+            return gain
+    return 1.0
 MODEL_VALID_DIM = 56                 # model-idx 3 of the --ssim list (pseudo_codec.py:18-19)
 PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("round4_bench_pmc.json", "round3_bench_pmc.json", "round2_bench_pmc.json")]
 
@@ -460,7 +469,7 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
             for label, (fl, tt, n) in sorted(d["classes"].items(), key=lambda kv: -kv[1][1]):
                 # fl = direct-convolution flops (2 Cin k^2 Cout per valid output pixel); a Winograd launch
                 # executes 1 / 2.25 of them: `achieved` / `frac` are executed matrix-core flops (<= peak)
-                gain = WINOGRAD_GAIN if kernel.startswith("wino_") else 1.0
+                gain = winograd_gain(kernel)
                 row = {"class": label, "kernel": kernel, "launches": n, "avg_launch_ms": round(tt / n * 1e3, 4),
                        "gflop_per_launch": round(fl / gain / n / 1e9, 3), "achieved": round(fl / gain / tt / 1e12, 2),
                        "frac": round(fl / gain / tt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
@@ -470,15 +479,18 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         if per_kernel:
             kernel = max(per_kernel, key=lambda k: per_kernel[k]["seconds"])
             d = per_kernel[kernel]
-            gain = WINOGRAD_GAIN if kernel.startswith("wino_") else 1.0
+            gain = winograd_gain(kernel)
             direct = d["flops"] / d["seconds"] / 1e12          # direct-convolution flops of SURVEY 8d / time
             ach = direct / gain                                # what the algorithm executes on the matrix cores
             roof = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "launches": d["launches"],
                     "avg_launch_ms": round(d["seconds"] / d["launches"] * 1e3, 4), "traffic": None}
             if gain != 1.0:
-                roof["algorithm"] = "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 matrix multiply-adds per 2x2 outputs " \
-                                    "instead of 36; achieved / frac = executed flops, direct_equivalent = x 2.25"
+                roof["algorithm"] = ("Winograd F(4x2,3x3) on v_mfma_f32_32x32x2_f32: 24 matrix multiply-adds per 4x2 outputs "
+                                     "instead of 72; achieved / frac = executed flops, direct_equivalent = x 3"
+                                     if gain == 3.0 else
+                                     "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 matrix multiply-adds per 2x2 outputs "
+                                     "instead of 36; achieved / frac = executed flops, direct_equivalent = x 2.25")
                 roof["direct_equivalent"] = round(direct, 2)
             roof.update(pmc_evidence(kernel, d["flops"] / d["launches"]))
         conv_s = sum(v["seconds"] for v in per_kernel.values()) / max(args.steps, 1)

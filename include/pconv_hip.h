@@ -290,6 +290,20 @@ int pconv_conv3x3_wino(const float *in, const float *packed_u, const float *bias
                        const int32_t *col_limit, int npart, const float *residual, int trim,
                        int d2w, const long long *views, void *stream);
 
+/* The same layers by Winograd F(4x2, 3x3) (csrc/wino42.hip): F(4, 3) vertically, F(2, 3) horizontally --
+ * 3 instead of 4 (direct: 9) multiply-adds per input channel, output channel and pixel.  Same arguments and
+ * epilogues as pconv_conv3x3_wino; takes the layers pconv_wino42_supported(...) accepts: cin % 24 == 0,
+ * cout >= 32, at least 4 output rows, output width even (d2w: cout % 4 == 0).  Results differ from
+ * pconv_conv2d's fmaf chain by rounding (~3e-6 relative; model_zoo_v2.py:41-45,83-86,158-164 are fp32
+ * nn.Conv2d layers cuDNN runs with Winograd as well). */
+long long pconv_wino42_packed_size(int cout, int cin);
+int pconv_wino42_pack_weight(const float *w, float *packed, int cout, int cin, void *stream);
+int pconv_wino42_supported(int cin, int h, int w, int cout, int d2w);
+int pconv_conv3x3_wino42(const float *in, const float *packed_u, const float *bias, float *out,
+                       int tn, int cin, int h, int w, int cout, int act, const float *slope,
+                       const int32_t *col_limit, int npart, const float *residual, int trim,
+                       int d2w, const long long *views, void *stream);
+
 /* PseudoGDNV2.forward (PseudoContextV2.py:133-216) in one launch on the same
  * kernel: out = in / sqrt(beta + gamma * in^2) over channels (inverse: in * sqrt),
  * zeros from each tile's col_limit on (the reference's mask).  in, out

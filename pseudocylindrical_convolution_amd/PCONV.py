@@ -1107,10 +1107,33 @@ def packed_wino_weight(owner, weight, stream):
     return packed
 
 
+CONV3X3_DEFAULT = "wino42"
+
+
 def conv3x3_mode():
-    """'wino' (default) or 'direct' (PCONV_CONV3X3=direct): which kernel takes the 3x3 stride-1 layers"""
+    """which kernel takes the 3x3 stride-1 layers (PCONV_CONV3X3): 'wino42' = Winograd F(4x2, 3x3)
+    (csrc/wino42.hip) where it takes the layer, F(2x2, 3x3) elsewhere; 'wino' = F(2x2, 3x3)
+    (csrc/wino.hip); 'direct' = the fmaf-chain kernel the oracle restates bit for bit"""
     import os
-    return "direct" if os.environ.get("PCONV_CONV3X3", "wino")[0] == "d" else "wino"
+    mode = os.environ.get("PCONV_CONV3X3", CONV3X3_DEFAULT)
+    if mode[0] == "d":
+        return "direct"
+    return "wino42" if mode == "wino42" else "wino"
+
+
+def packed_wino42_weight(owner, weight, stream):
+    """U = G6 g G4t of a 3x3 weight in the layout of pconv_conv3x3_wino42, cached like packed_conv_weight"""
+    from .PCONV_operator import backend
+    key = (weight.data_ptr(), weight._version, weight.device, backend.param_epoch())
+    cached = getattr(owner, "_pconv_packed_wino42", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    size = int(_native.hip_lib().pconv_wino42_packed_size(cout, cin))
+    packed = torch.empty(size, dtype=torch.float32, device=weight.device)
+    call("pconv_wino42_pack_weight", _ptr(weight.detach().contiguous()), _ptr(packed), cout, cin, stream)
+    owner._pconv_packed_wino42 = (key, packed)
+    return packed
 
 
 def _aligned8(t):
@@ -1235,10 +1258,15 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     residual = _like_output(residual, out, "tile_conv2d: residual")
     # 3x3 stride-1 layers: Winograd F(2x2, 3x3) on the matrix cores (csrc/wino.hip) unless
     # PCONV_CONV3X3=direct asks for the fmaf-chain kernel (the bit-exact form the oracle restates)
-    want_wino = k == 3 and stride == 1 and not sigmoid and gate is None and conv3x3_mode() == "wino"
-    wino = (want_wino and _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1 and
-            _aligned8(out) and (residual is None or _aligned8(residual)))
-    if want_wino and not wino:
+    mode = conv3x3_mode()
+    want_wino = k == 3 and stride == 1 and not sigmoid and gate is None and mode != "direct"
+    aligned = want_wino and _aligned8(out) and (residual is None or _aligned8(residual))
+    # F(4x2, 3x3) works on 64-cout blocks: a 96-cout layer would run a third of them empty (and its 24 chunks are
+    # head and tail of the unrolled loop, no steady state): measured 0.475 vs 0.374 ms, it stays with F(2x2, 3x3)
+    wino42 = (aligned and mode == "wino42" and cout % 64 == 0 and
+              _native.hip_lib().pconv_wino42_supported(cin, h, w, cout, 1 if d2w else 0) == 1)
+    wino = aligned and not wino42 and _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1
+    if want_wino and not (wino or wino42):
         # a plain 3x3 stride-1 layer that Winograd was selected for went to the direct kernel (shape not
         # taken, or output / residual rows not 8-byte aligned): counted, so that the choice is never silent
         key = (cin, h, w, cout, bool(d2w))
@@ -1247,9 +1275,10 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(x.device))
-    if wino:
+    if wino or wino42:
         views = _views(x, out, residual)
-        call("pconv_conv3x3_wino", _ptr(x), _ptr(packed_wino_weight(owner, weight, stream)),
+        call("pconv_conv3x3_wino42" if wino42 else "pconv_conv3x3_wino", _ptr(x),
+             _ptr(packed_wino42_weight(owner, weight, stream) if wino42 else packed_wino_weight(owner, weight, stream)),
              _ptr(bias.detach()) if bias is not None else None, _ptr(out), tn, cin, h, w, cout,
              1 if slope is not None else 0, _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit),
              int(npart), _ptr(residual), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
@@ -1263,6 +1292,7 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
-        kernel = "wino_conv3x3_kernel" if wino else conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w)
+        kernel = "wino42_conv3x3_kernel" if wino42 else ("wino_conv3x3_kernel" if wino else
+                                                         conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w))
         probe.records.append((kernel, "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo), flops, e0, e1))
     return out

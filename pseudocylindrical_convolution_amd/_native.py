@@ -61,6 +61,10 @@ _HIP_SIGNATURES = {
     "pconv_wino_pack_weight": [P, P, I, I, P],
     "pconv_wino_supported": [I, I, I, I, I],
     "pconv_conv3x3_wino": [P, P, P, P, I, I, I, I, I, I, P, P, I, P, I, I, P, P],
+    "pconv_wino42_packed_size": [I, I],
+    "pconv_wino42_pack_weight": [P, P, I, I, P],
+    "pconv_wino42_supported": [I, I, I, I, I],
+    "pconv_conv3x3_wino42": [P, P, P, P, I, I, I, I, I, I, P, P, I, P, I, I, P, P],
     # entropy wavefront
     "pconv_dinput2": [P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "pconv_ctx_pad_run2": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
@@ -135,6 +139,7 @@ def hip_lib():
         lib.pconv_ee_stream.argtypes = [P, I, POINTER(c_size_t)]
         lib.pconv_ee_stream.restype = POINTER(c_uint8)
         lib.pconv_wino_packed_size.restype = c_longlong
+        lib.pconv_wino42_packed_size.restype = c_longlong
         _hip = lib
     return _hip
 

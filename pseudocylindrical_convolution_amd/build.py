@@ -28,6 +28,7 @@ HIP_SOURCES = [
     "entropy_engine.hip",
     "conv.hip",
     "wino.hip",
+    "wino42.hip",
     "backward.hip",
     "engine.cpp",
     "coder.cpp",  # the engine drives the arithmetic coder natively

@@ -57,9 +57,11 @@ def test_wino_matches_direct_kernel_and_float64(cfg, hip_backend, monkeypatch):
 
 
 def test_wino_is_the_default_and_direct_stays_selectable(hip_backend, monkeypatch):
+    """default (round 4): F(4x2, 3x3) for the layers with 64-multiple couts it takes, F(2x2, 3x3) for the rest of the
+    3x3 stride-1 layers (a 96-cout layer here)"""
     x, wt, b, _ = data(1, 96, 6, 66, 96)
     monkeypatch.delenv("PCONV_CONV3X3", raising=False)
-    assert P().conv3x3_mode() == "wino"
+    assert P().conv3x3_mode() == "wino42"
     owner = type("Owner", (), {})()
     rec = type("Probe", (), {"records": []})()
     monkeypatch.setattr(P(), "conv_probe", rec)
