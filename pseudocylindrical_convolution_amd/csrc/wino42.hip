@@ -38,6 +38,15 @@
 
 namespace {
 
+#ifdef PCONV_W42_STAMP
+// profiling build (tools/gpu_probe_wino42_stamps.py): s_memtime of one workgroup's phases, per wave:
+// [start, prologue done, main loop done, way out done, barrier wait cycles of the steady chunks, steady chunks]
+__device__ unsigned long long w42_stamps[8][6];
+#define W42_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define W42_STAMP(var)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -252,6 +261,7 @@ template <bool RES, bool D2W>
 __global__ __launch_bounds__(kThreads) void wino42_conv3x3_kernel(
     const float *__restrict__ in, const float *__restrict__ upk, float *out, int cin, int cin_pad, int h,
     int w, int cout, int ho, int wo, int tiles_r, int tiles_c, int cblocks, WView vin, WView vout, WEpilogue ep) {
+  W42_STAMP(st_start);
   extern __shared__ float lds[];
   float *Ps = lds, *Vs = lds + PRING * PBUF, *Us = lds + PRING * PBUF + 2 * VSZ;
 
@@ -408,14 +418,22 @@ __global__ __launch_bounds__(kThreads) void wino42_conv3x3_kernel(
   // patch(chunk+1) -- and with it everything older, weights(chunk) included -- must have landed; weights(chunk+2),
   // issued a moment ago, stays in flight (counted wait).  Then everybody's: V(chunk) is complete (lgkmcnt(0): this
   // thread's LDS writes) and the MFMAs of chunk-1, last readers of V's other buffer, are done.
+#ifdef PCONV_W42_STAMP
+  unsigned long long st_bar = 0, st_n = 0;
+#endif
+  W42_STAMP(st_prologue);
   auto body = [&](auto us_c, auto vb_c, auto steady_c, int chunk) {
     constexpr int US = decltype(us_c)::value;
     constexpr int vb = decltype(vb_c)::value;
     constexpr bool STEADY = decltype(steady_c)::value;
+    W42_STAMP(tb0);
     if (STEADY)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ULD) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PCONV_W42_STAMP
+    if (STEADY) st_bar += __builtin_readcyclecounter() - tb0, st_n += 1;
+#endif
     if (!STEADY) issue_patch(chunk + 2, vb, true);  // (that stage was read by the transform of this chunk, before the barrier)
     float a[2][2], bv[2][2];
     W42Rows rows;
@@ -450,6 +468,7 @@ __global__ __launch_bounds__(kThreads) void wino42_conv3x3_kernel(
   for (; c6 + 2 * UNROLL <= nchunk; c6 += UNROLL) group(integral_constant<bool, true>{}, c6);
 #pragma unroll 1
   for (; c6 < nchunk; c6 += UNROLL) group(integral_constant<bool, false>{}, c6);
+  W42_STAMP(st_loop);
   __syncthreads();  // all MFMAs done: the stage memory becomes the exchange buffer
 
   // ---- output transform + epilogue ----
@@ -553,6 +572,12 @@ __global__ __launch_bounds__(kThreads) void wino42_conv3x3_kernel(
       }
     }
   }
+#ifdef PCONV_W42_STAMP
+  if (blockIdx.x == gridDim.x / 2 + 1 && lane == 0) {
+    unsigned long long *o = w42_stamps[wave];
+    o[0] = st_start, o[1] = st_prologue, o[2] = st_loop, o[3] = __builtin_readcyclecounter(), o[4] = st_bar, o[5] = st_n;
+  }
+#endif
 }
 
 inline WView dense_view(int c, int h, int w) { return {(long long)c * h * w, (long long)h * w, w}; }
@@ -565,6 +590,12 @@ inline bool view_ok(const WView &v, int c, int h, int w) {
 }
 
 }  // namespace
+
+#ifdef PCONV_W42_STAMP
+extern "C" int pconv_wino42_read_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(w42_stamps), sizeof(w42_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // floats of the packed F(4x2, 3x3) weights of a (cout, cin, 3, 3) layer
 extern "C" long long pconv_wino42_packed_size(int cout, int cin) {
