@@ -393,7 +393,8 @@ def parse_args(argv=None):
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed passes before the warm-up so that the caching allocator reaches steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1024x2048", help="HxW of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="2048x4096",
+                    help="HxW of the CPU baseline sample (default: the metric frame, ~80 s on a 16-core share; 1024x2048: ~20 s)")
     ap.add_argument("--no-check", action="store_true", help="skip the round-trip / stationarity assertions")
     args = ap.parse_args(argv)
     if args.height is None:
@@ -492,7 +493,7 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
                                      "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 matrix multiply-adds per 2x2 outputs "
                                      "instead of 36; achieved / frac = executed flops, direct_equivalent = x 2.25")
                 roof["direct_equivalent"] = round(direct, 2)
-            roof.update(pmc_evidence(kernel, d["flops"] / d["launches"]))
+            roof.update(pmc_evidence(kernel, d["flops"] / gain / d["launches"]))  # (executed flops, as in the table)
         conv_s = sum(v["seconds"] for v in per_kernel.values()) / max(args.steps, 1)
         frames_total = max(totals["frames"], 1.0)
         config = {"workload": load.describe(), "frames_per_gpu": load.F,

@@ -27,6 +27,8 @@ def short(name):
     # the Winograd kernel's instantiations (residual / plain / Dtow way out) are one kernel to bench.py
     if name.startswith("wino_conv3x3_kernel<"):
         name = "wino_conv3x3_kernel"
+    if name.startswith("wino42_conv3x3_kernel<"):
+        name = "wino42_conv3x3_kernel"
     return name
 
 
