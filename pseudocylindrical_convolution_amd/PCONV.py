@@ -1118,7 +1118,7 @@ def conv3x3_mode():
     mode = os.environ.get("PCONV_CONV3X3", CONV3X3_DEFAULT)
     if mode[0] == "d":
         return "direct"
-    return "wino42" if mode == "wino42" else "wino"
+    return mode if mode in ("wino42", "wino42!") else "wino"   # "wino42!": every layer the kernel takes (tests / probes)
 
 
 def packed_wino42_weight(owner, weight, stream):
@@ -1263,7 +1263,9 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     aligned = want_wino and _aligned8(out) and (residual is None or _aligned8(residual))
     # F(4x2, 3x3) works on 64-cout blocks: a 96-cout layer would run a third of them empty (and its 24 chunks are
     # head and tail of the unrolled loop, no steady state): measured 0.475 vs 0.374 ms, it stays with F(2x2, 3x3)
-    wino42 = (aligned and mode == "wino42" and cout % 64 == 0 and
+    # ... and on 8-row blocks: with more than an eighth of the computed rows outside the tensor (34 -> 40, 18 -> 24
+    # output rows: the "+1 halo" layers of ResidualBlockV2 at the small scales) F(2x2)'s 4-row blocks are level or ahead
+    wino42 = (aligned and (mode == "wino42!" or (mode == "wino42" and cout % 64 == 0 and (ho + 7) // 8 * 8 * 8 <= 9 * ho)) and
               _native.hip_lib().pconv_wino42_supported(cin, h, w, cout, 1 if d2w else 0) == 1)
     wino = aligned and not wino42 and _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1
     if want_wino and not (wino or wino42):

@@ -51,7 +51,7 @@ def test_wino42_matches_direct_kernel_and_float64(cfg, hip_backend, monkeypatch)
     for slope in (None, sl):
         want = ref64 if slope is None else torch.where(ref64 < 0, ref64 * slope.double().view(1, -1, 1, 1), ref64)
         yd = conv(monkeypatch, "direct", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope.to(DEV) if slope is not None else None).cpu()
-        yw = conv(monkeypatch, "wino42", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope.to(DEV) if slope is not None else None).cpu()
+        yw = conv(monkeypatch, "wino42!", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope.to(DEV) if slope is not None else None).cpu()
         assert yw.shape == yd.shape
         ed, ew = (yd.double() - want).abs().max().item(), (yw.double() - want).abs().max().item()
         assert ed < 2e-5 and ew < 3e-5, "direct %g, winograd F(4x2) %g from float64" % (ed, ew)
@@ -59,19 +59,28 @@ def test_wino42_matches_direct_kernel_and_float64(cfg, hip_backend, monkeypatch)
     assert [r[0].split("<")[0] for r in rec.records] == ["conv_mfma_kernel", "wino42_conv3x3_kernel"] * 2
 
 
-def test_wino42_falls_back_to_wino_where_it_does_not_fit(hip_backend, monkeypatch):
-    """cin % 24 != 0 or couts that do not fill 64-cout blocks: the F(2x2) kernel takes the layer (fewer than four
-    output rows: the direct kernel); the default mode is wino42"""
+def test_wino42_dispatch_rules(hip_backend, monkeypatch):
+    """default mode "wino42": F(4x2) for 64-multiple couts whose output rows fill the 8-row blocks to 8/9 at least,
+    F(2x2) for the rest of what Winograd takes (cin % 24 != 0: F(4x2) does not take it at all), the direct kernel
+    below four output rows; "wino42!" (tests, probes) sends every layer the kernel takes to it"""
     rec = type("Probe", (), {"records": []})()
     monkeypatch.setattr(P(), "conv_probe", rec)
     monkeypatch.delenv("PCONV_CONV3X3", raising=False)
+    assert P().conv3x3_mode() == "wino42"
     for (cfg, want) in (((1, 32, 10, 66, 64), "wino_conv3x3_kernel"), ((1, 96, 5, 66, 128), "conv_mfma_kernel"),
                         ((1, 96, 10, 66, 96), "wino_conv3x3_kernel"), ((1, 96, 10, 66, 128), "wino42_conv3x3_kernel"),
-                        ((1, 192, 10, 66, 192), "wino42_conv3x3_kernel")):
+                        ((1, 192, 10, 66, 192), "wino42_conv3x3_kernel"), ((1, 192, 68, 66, 192), "wino42_conv3x3_kernel"),
+                        ((1, 192, 36, 66, 192), "wino_conv3x3_kernel"), ((1, 192, 20, 66, 192), "wino_conv3x3_kernel")):
         x, wt, b, _ = data(*cfg)
         rec.records.clear()
         P().tile_conv2d(type("Owner", (), {})(), x.to(DEV), wt.to(DEV), b.to(DEV), 1)
         assert rec.records[0][0].split("<")[0] == want, cfg
+    monkeypatch.setenv("PCONV_CONV3X3", "wino42!")
+    for cfg in ((1, 96, 10, 66, 96), (1, 192, 36, 66, 192)):
+        x, wt, b, _ = data(*cfg)
+        rec.records.clear()
+        P().tile_conv2d(type("Owner", (), {})(), x.to(DEV), wt.to(DEV), b.to(DEV), 1)
+        assert rec.records[0][0].split("<")[0] == "wino42_conv3x3_kernel", cfg
 
 
 @pytest.mark.parametrize("cfg", [(16, 192, 10, 70, 192), (32, 96, 6, 134, 64), (16, 192, 18, 262, 192)])
@@ -93,7 +102,7 @@ def test_wino42_epilogue_views_and_dead_columns(cfg, hip_backend, monkeypatch):
     args = (wt.to(DEV), b.to(DEV), 1, sl.to(DEV), limit, 16)
     for (xin, rin, ring) in ((x.to(DEV), res.to(DEV), 0), (inside(x, 2), inside(res, 2), 2), (inside(x, 1), res.to(DEV), 2)):
         yd = conv(monkeypatch, "direct", xin, *args, residual=rin, trim=True, ring=ring)
-        yw = conv(monkeypatch, "wino42", xin, *args, residual=rin, trim=True, ring=ring)
+        yw = conv(monkeypatch, "wino42!", xin, *args, residual=rin, trim=True, ring=ring)
         assert (yw - yd).abs().max().item() < 3e-5
         for t in range(tn):
             lim = int(limit[t % 16])
@@ -102,7 +111,7 @@ def test_wino42_epilogue_views_and_dead_columns(cfg, hip_backend, monkeypatch):
             buf = yw._pconv_ring[0]
             assert tuple(buf.shape) == (tn, cout, ho + 2 * ring, wo + 2 * ring)
     yd = conv(monkeypatch, "direct", x.to(DEV), wt.to(DEV), b.to(DEV), 1, None, limit, 16)
-    yw = conv(monkeypatch, "wino42", x.to(DEV), wt.to(DEV), b.to(DEV), 1, None, limit, 16)
+    yw = conv(monkeypatch, "wino42!", x.to(DEV), wt.to(DEV), b.to(DEV), 1, None, limit, 16)
     assert (yw - yd).abs().max().item() < 3e-5
 
 
@@ -112,10 +121,10 @@ def test_wino42_depth_to_width_store(cfg, hip_backend, monkeypatch):
     x, wt, b, sl = data(*cfg, seed=11)
     limit = torch.tensor([w - 2, 40, 64, 3] * 4, dtype=torch.int32).to(DEV)
     for slope in (None, sl.to(DEV)):
-        plain = conv(monkeypatch, "wino42", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16)
+        plain = conv(monkeypatch, "wino42!", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16)
         shuffled = P().DtowOp(2, True, 0, False).forward(plain)[0].clone()
         for ring in (0, 2):
-            fused = conv(monkeypatch, "wino42", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16, d2w=True, ring=ring)
+            fused = conv(monkeypatch, "wino42!", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16, d2w=True, ring=ring)
             assert tuple(fused.shape) == tuple(shuffled.shape)
             assert torch.equal(fused, shuffled)                     # same arithmetic, another store
         direct = conv(monkeypatch, "direct", x.to(DEV), wt.to(DEV), b.to(DEV), 1, slope, limit, 16, d2w=True)
@@ -135,7 +144,7 @@ def test_wino42_relative_error_at_other_scales(xscale, wscale, hip_backend, monk
     b = torch.zeros(cout)
     ref64 = torch.nn.functional.conv2d(x.double(), wt.double())
     scale = torch.nn.functional.conv2d(x.double() ** 2, wt.double() ** 2).sqrt()
-    yw = conv(monkeypatch, "wino42", x.to(DEV), wt.to(DEV), b.to(DEV), 1).cpu().double()
+    yw = conv(monkeypatch, "wino42!", x.to(DEV), wt.to(DEV), b.to(DEV), 1).cpu().double()
     rw = ((yw - ref64).abs() / scale).max().item()
     assert rw < 2e-5, "relative error of F(4x2, 3x3): %g" % rw
     assert torch.isfinite(yw).all()

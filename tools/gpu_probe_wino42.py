@@ -29,7 +29,7 @@ cases = [  # tn, cin, cout, rows (out), cols (out), residual+trim, d2w
 ]
 if os.environ.get("PCONV_PROBE_SHORT"):
     cases = [cases[0], cases[4], cases[6]]
-modes = ("direct", "wino", "wino42") if not os.environ.get("PCONV_PROBE_NODIRECT") else ("wino", "wino42")
+modes = ("direct", "wino", "wino42!") if not os.environ.get("PCONV_PROBE_NODIRECT") else ("wino", "wino42!")
 for (tn, cin, cout, rows, cols, res, d2w) in cases:
     x = torch.randn(tn, cin, rows + 2, cols + 2, device=dev)
     conv = torch.nn.Conv2d(cin, cout, 3).to(dev)

@@ -8,7 +8,7 @@ from pseudocylindrical_convolution_amd.PCONV_operator import set_weight
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 W16 = np.asarray(set_weight(16, True), dtype=np.float32)
-os.environ["PCONV_CONV3X3"] = "wino42"
+os.environ["PCONV_CONV3X3"] = "wino42!"
 lib = _native.hip_lib()
 for (tn, cin, cout, rows, cols, res, d2w) in ((16, 192, 192, 64, 2048, True, False), (16, 192, 768, 32, 1024, False, True)):
     x = torch.randn(tn, cin, rows + 2, cols + 2, device=dev)
