@@ -168,6 +168,7 @@ struct Group {
   std::vector<int32_t> step_row;  // first table row of each step (x nimg), +1 end
   std::vector<int32_t> sym;
   StepPool *pool = nullptr;
+  bool zeroed = false;  // ctx / act hold no uninitialised memory any more (clear())
 };
 
 }  // namespace
@@ -426,10 +427,17 @@ struct pconv_entropy_engine {
     return PCONV_OK;
   }
 
+  // The context and activation buffers are zeroed ONCE per group (r4; 2 GB per two-frame group and call before:
+  // 6 ms of the 8-frame step).  What must be zero stays zero -- dead columns, the left halo columns and the rows
+  // beyond the first / last tile are never written -- and everything else is either rewritten before it is read
+  // (every live position and its halo / wrap entries, by the producer of the value) or read through a zero weight
+  // (the causal mask: a stale value of the previous call is finite, so fmaf(stale, 0, acc) == acc).
   int clear(Group &g) {
     HIP_TRY(hipMemsetAsync(g.counter_d, 0, 64, g.stream));  // table-kernel block counter, scatter relay word
+    if (g.zeroed) return PCONV_OK;
     HIP_TRY(hipMemsetAsync(g.ctx, 0, ctx_elems(g.nimg) * 4, g.stream));
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(g.act[l], 0, act_elems(l, g.nimg) * 4, g.stream));
+    g.zeroed = true;
     return PCONV_OK;
   }
 

@@ -208,3 +208,21 @@ def test_engine_wide_models_equal_per_op_path(vd, hip_backend, tmp_path):
     assert tuple(sym.shape) == (32, vd // 4, 10, 64)
     assert torch.equal(eng._engine("dec", 10, 64, 2).decode(streams), sym)
     assert torch.equal(eng._engine("dec", 10, 64, 1).decode(streams[1:]), sym[16:])
+
+
+def test_engine_buffers_are_zeroed_once_not_per_call(hip_backend):
+    """the engine clears its context / activation buffers once per group (csrc/engine.cpp clear()): a second call
+    on the same engine runs over the first call's values -- everything it reads through a non-zero weight has been
+    rewritten by then.  Frames B after frames A on one engine == frames B on a fresh engine, streams and symbols."""
+    from pseudocylindrical_convolution_amd.engine import CodecEngine
+    enc, dec = _codec()
+    a, b = _frames(2, 512, 1024, seed=31), _frames(2, 512, 1024, seed=32)
+    used = CodecEngine(56, 0, enc, dec)
+    sa = used.encode(a)
+    used.decode(sa, 512, 1024)
+    sb = used.encode(b)
+    fresh = CodecEngine(56, 0, enc, dec)
+    assert sb == fresh.encode(b) and sb != sa
+    sym = fresh.symbols(b)
+    assert torch.equal(used._engine("dec", sym.shape[2], sym.shape[3], 2).decode(sb), sym)
+    assert torch.equal(used.decode(sb, 512, 1024), fresh.decode(sb, 512, 1024))
