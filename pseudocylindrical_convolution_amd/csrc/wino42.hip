@@ -12,10 +12,11 @@
 // than the direct form) with the same accumulator budget -- three quarters of the CU's register file -- the
 // same LDS footprint and the same number of matrix instructions per workgroup, which now covers 64 couts x
 // 64 tiles of 4 x 2 = 8 x 64 output pixels (wino.hip: 96 couts x 4 x 64 pixels).  Only the vertical transforms
-// carry F(4, 3)'s larger constants (4, 5, 8, 1/24): the rounding error is about 3 x that of wino.hip, an order
-// of magnitude below the codec's 1e-4 budget (tests/test_gpu_wino.py); F(4x4, 3x3) -- 2.25 per output --
-// would need 36 accumulator blocks, i.e. 32 couts x 64 tiles per workgroup at twice the weight traffic and
-// transform work per matrix instruction.
+// carry F(4, 3)'s larger constants (4, 5, 8, 1/24): the rounding error is about 3 x that of wino.hip (1.1e-5
+// against float64 on unit-scale outputs), an order of magnitude below the codec's 1e-4 budget
+// (tests/test_gpu_wino42.py).  F(4x4, 3x3) -- 2.25 per output -- would need 36 accumulator blocks, i.e. 64
+// couts x 32 tiles per workgroup: 18 instead of 24 matrix instructions per chunk under the same transform / DMA
+// / barrier cost per chunk (priced in DESIGN.md section 4: ~5 % faster at 3 x the error; not built).
 //
 // Structure = wino.hip's, re-tiled:
 //   * a workgroup = 8 waves; wave w owns the GEMMs xi = 3w .. 3w+2: three 64 x 64 accumulator blocks of
