@@ -41,6 +41,11 @@ class BitSink {
     acc_ = 0;
     fill_ = 0;
   }
+  // room for `nbytes` more bytes (+ the accumulator's): lets a caller that knows an upper bound of what it is
+  // going to put skip the per-put capacity check's reallocation path
+  void reserve(size_t nbytes) {
+    if (len_ + nbytes + 16 > bytes_.size()) bytes_.resize((len_ + nbytes + 16) * 2 + 4096);
+  }
   // append the low `n` bits of v, most significant first (n <= 32): a 64-bit accumulator,
   // whole bytes leave it as soon as they are complete
   inline void put(uint64_t v, int n) {
@@ -82,23 +87,33 @@ class BitSource {
     acc_ = 0;
     have_ = 0;
   }
-  // next n bits (n <= 32), zeros past the end (ArithmeticCoder.cpp:121-126)
-  uint32_t get(int n) {
-    while (have_ < n) {
-      uint64_t b = pos_ < n_ ? p_[pos_] : 0;
-      pos_++;
-      acc_ = (acc_ << 8) | b;
-      have_ += 8;
+  // next n bits (n <= 32), zeros past the end (ArithmeticCoder.cpp:121-126).  The accumulator is refilled four
+  // bytes at a time while the stream has them (one unaligned big-endian load instead of a byte loop).
+  inline uint32_t get(int n) {
+    if (have_ < n) {
+      if (pos_ + 4 <= n_) {
+        uint32_t w;
+        memcpy(&w, p_ + pos_, 4);
+        acc_ = (acc_ << 32) | __builtin_bswap32(w);
+        pos_ += 4;
+        have_ += 32;
+      } else {
+        while (have_ < n) {
+          uint64_t b = pos_ < n_ ? p_[pos_] : 0;
+          pos_++;
+          acc_ = (acc_ << 8) | b;
+          have_ += 8;
+        }
+      }
     }
     have_ -= n;
-    uint32_t v = (uint32_t)((acc_ >> have_) & ((n == 32) ? 0xffffffffull : ((1ull << n) - 1)));
-    return v;
+    return (uint32_t)((acc_ >> have_) & ((n == 32) ? 0xffffffffull : ((1ull << n) - 1)));
   }
 
  private:
   const uint8_t *p_ = nullptr;
   size_t n_ = 0, pos_ = 0;
-  uint64_t acc_ = 0;
+  uint64_t acc_ = 0;  // (have_ <= 31 before a refill: 63 bits at most are live)
   int have_ = 0;
 };
 
@@ -239,6 +254,67 @@ struct pconv_coder {
   }
 };
 
+// The codec's rows (8 symbols, total 65536) in one loop with the coder's state -- interval, code word, bit
+// reader -- in registers: read_symbol_8x65536 symbol by symbol keeps them in the object (every call reloads and
+// stores them, and its error paths make the compiler assume they may alias).  Same operations, same order, same
+// checks; rows of another shape end the fast loop (the caller goes on with the general path).  Returns the
+// number of rows done, or < 0.
+template <typename T>
+static int decode_rows_8x65536(pconv_coder *c, const int32_t *table, T *out, int n) {
+  uint64_t low = c->low, high = c->high, code = c->code;
+  BitSource src = c->source;
+  int i = 0, rc = 0;
+  for (; i < n; i++) {
+    const uint32_t *t = reinterpret_cast<const uint32_t *>(table + (size_t)i * 9);
+    if (t[8] != 65536u) break;
+    const uint64_t range = high - low + 1;
+    if (low >= high || range < kMinRange || range > kMaxRange) {
+      rc = c->fail(PCONV_CODER_ESTATE, "Assertion error: Range out of range");
+      break;
+    }
+    const uint64_t offset = code - low;
+    uint64_t thr[9];
+#pragma GCC unroll 9
+    for (int k = 0; k < 9; k++) thr[k] = ((uint64_t)t[k] * range) >> 16;
+    unsigned symbol = 0;
+#pragma GCC unroll 7
+    for (int k = 1; k < 8; k++) symbol += thr[k] <= offset;
+    const uint64_t lo_t = thr[symbol], hi_t = thr[symbol + 1];
+    if (t[symbol] == t[symbol + 1]) {
+      rc = c->fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
+      break;
+    }
+    if (offset < lo_t || hi_t <= offset) {
+      rc = c->fail(PCONV_CODER_EDESYNC, "Assertion error");
+      break;
+    }
+    high = low + hi_t - 1;
+    low = low + lo_t;
+    // renormalise<false>() on the local state
+    const int agree = clz32((uint32_t)((low ^ high) & kMask));
+    if (agree > 0) {
+      code = ((code << agree) & kMask) | src.get(agree);
+      low = (low << agree) & kMask;
+      high = ((high << agree) & kMask) | ((1ull << agree) - 1);
+    }
+    const uint32_t pattern = (uint32_t)((low & ~high & (kMask >> 1)) << 1);
+    const int squeeze = clz32(~pattern);
+    if (squeeze > 0) {
+      code = (code & kTop) | ((code << squeeze) & (kMask >> 1)) | src.get(squeeze);
+      low = (low << squeeze) & (kMask >> 1);
+      high = ((high << squeeze) & (kMask >> 1)) | kTop | ((1ull << squeeze) - 1);
+    }
+    if (code < low || code > high) {
+      rc = c->fail(PCONV_CODER_EDESYNC, "Assertion error: Code out of range");
+      break;
+    }
+    out[i] = (T)symbol;
+  }
+  c->low = low, c->high = high, c->code = code;
+  c->source = src;
+  return rc < 0 ? rc : i;
+}
+
 template <typename T>
 static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, int n) {
   if (!c || ncode <= 0) return PCONV_CODER_EARG;
@@ -246,7 +322,12 @@ static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, 
   if (n <= 0) return 0;
   if (!table || !out) return c->fail(PCONV_CODER_EARG, "null table or output");
   const int stride = ncode + 1;
-  for (int i = 0; i < n; i++) {
+  int first = 0;
+  if (ncode == 8) {
+    first = decode_rows_8x65536(c, table, out, n);
+    if (first < 0) return first;
+  }
+  for (int i = first; i < n; i++) {
     const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
     const int s = (ncode == 8 && row[8] == 65536u) ? c->read_symbol_8x65536(row)
                                                    : c->read_symbol(row, (uint32_t)ncode, row[ncode]);
@@ -302,7 +383,58 @@ int pconv_coder_encodes(pconv_coder *c, const int32_t *table, int ncode, const i
   if (n <= 0) return 0;
   if (!table || !symbols) return c->fail(PCONV_CODER_EARG, "null table or symbols");
   const int stride = ncode + 1;
-  for (int i = 0; i < n; i++) {
+  int i = 0;
+  if (ncode == 8) {
+    // the codec's rows (8 symbols, total 65536): narrow<true>() with the interval in registers and the two
+    // divisions by the total as shifts; rows of another shape end the fast loop
+    uint64_t low = c->low, high = c->high, pending = c->pending;
+    c->sink.reserve((size_t)n * 5 + 64);  // (<= 33 bits leave the state per symbol, deferred bits included)
+    int rc = 0;
+    for (; i < n; i++) {
+      const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * 9);
+      if (row[8] != 65536u) break;
+      const uint32_t s = (uint32_t)symbols[i];
+      if (s >= 8u) {
+        rc = c->fail(PCONV_CODER_EARG, "symbol out of range");
+        break;
+      }
+      const uint64_t range = high - low + 1;
+      if (low >= high || range < kMinRange || range > kMaxRange) {
+        rc = c->fail(PCONV_CODER_ESTATE, "Assertion error: Range out of range");
+        break;
+      }
+      const uint32_t sym_low = row[s], sym_high = row[s + 1];
+      if (sym_low == sym_high) {
+        rc = c->fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
+        break;
+      }
+      high = low + ((sym_high * range) >> 16) - 1;
+      low = low + ((sym_low * range) >> 16);
+      const int agree = clz32((uint32_t)((low ^ high) & kMask));
+      if (agree > 0) {
+        const uint32_t top = (uint32_t)(low >> (kStateBits - agree));
+        const int firstbit = (top >> (agree - 1)) & 1;
+        c->sink.put(firstbit, 1);
+        if (pending) {
+          c->sink.put_run(firstbit ^ 1, pending);
+          pending = 0;
+        }
+        if (agree > 1) c->sink.put(top & ((1u << (agree - 1)) - 1), agree - 1);
+        low = (low << agree) & kMask;
+        high = ((high << agree) & kMask) | ((1ull << agree) - 1);
+      }
+      const uint32_t pattern = (uint32_t)((low & ~high & (kMask >> 1)) << 1);
+      const int squeeze = clz32(~pattern);
+      if (squeeze > 0) {
+        pending += squeeze;
+        low = (low << squeeze) & (kMask >> 1);
+        high = ((high << squeeze) & (kMask >> 1)) | kTop | ((1ull << squeeze) - 1);
+      }
+    }
+    c->low = low, c->high = high, c->pending = pending;
+    if (rc < 0) return rc;
+  }
+  for (; i < n; i++) {
     const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
     const uint32_t s = (uint32_t)symbols[i];
     if (s >= (uint32_t)ncode) return c->fail(PCONV_CODER_EARG, "symbol out of range");

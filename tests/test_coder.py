@@ -123,3 +123,62 @@ def test_missing_file_decodes_as_zero_stream(tmp_path):
     c.start_decoder()
     tab = torch.tensor([[0, 8192, 65536]], dtype=torch.int32)
     assert int(c.decodes(tab, 2, 1)[0]) == 0
+
+
+def _rows8(rng, n):
+    w = rng.gamma(0.3, 1.0, size=(n, 8)) + 1e-6
+    w = w / w.sum(1, keepdims=True)
+    c = np.floor(np.cumsum(w, 1) * (65536 - 8)).astype(np.int64) + np.arange(1, 9)
+    tab = np.concatenate([np.zeros((n, 1), np.int64), c], 1).astype(np.int32)
+    tab[:, 8] = 65536
+    sym = (rng.integers(0, 65536, n)[:, None] >= tab[:, 1:]).sum(1).astype(np.int32)
+    return tab, sym
+
+
+def test_rows_of_another_total_inside_a_batch(tmp_path):
+    """The 8-symbol / total-65536 rows have a loop of their own in the product (coder.cpp: the interval lives in
+    registers there); a row of another total ends it and the general path goes on.  Same bytes as the bit-at-a-time
+    restatement, and the stream decodes."""
+    rng = np.random.default_rng(5)
+    tab, sym = _rows8(rng, 600)
+    for r in (0, 1, 299, 300, 599):                      # rows whose total is 40000, not 65536
+        tab[r] = (tab[r].astype(np.int64) * 40000 // 65536).astype(np.int32)
+        tab[r, 1:] = np.maximum(tab[r, 1:], tab[r, :-1] + 1)
+        tab[r, 8] = max(int(tab[r, 8]), 40000)
+    want = _encode(coder_cpu.PyCoder, str(tmp_path / "o.bin"), tab, sym)
+    assert _encode(product.coder, str(tmp_path / "p.bin"), tab, sym) == want
+    assert (_decode(product.coder, str(tmp_path / "p.bin"), tab, len(sym)) == sym).all()
+
+
+def test_error_inside_a_batch_leaves_the_rows_before_it_coded(tmp_path):
+    rng = np.random.default_rng(6)
+    tab, sym = _rows8(rng, 200)
+    bad = tab.copy()
+    bad[120, 4] = bad[120, 3]                            # symbol 3 of row 120 has zero frequency
+    sym[120] = 3
+    c = product.coder(str(tmp_path / "z.bin"))
+    c.start_encoder()
+    with pytest.raises(product.CoderError, match="zero frequency"):
+        c.encodes(torch.from_numpy(bad), 8, torch.from_numpy(sym), 200)
+    # the coder's state is that after rows 0..119: go on with good rows and compare with a clean run
+    c.encodes(torch.from_numpy(tab[120:].copy()), 8, torch.from_numpy(sym[120:].copy()), 80)
+    c.end_encoder()
+    assert c.bytes() == _encode(product.coder, str(tmp_path / "g.bin"), tab, sym)
+    c2 = product.coder(str(tmp_path / "r.bin"))
+    c2.start_encoder()
+    sym2 = sym.copy()
+    sym2[50] = 8                                         # not a symbol of an 8-symbol row
+    with pytest.raises(product.CoderError, match="out of range"):
+        c2.encodes(torch.from_numpy(tab), 8, torch.from_numpy(sym2), 200)
+
+
+def test_decoder_reports_zero_frequency_and_survives_garbage(tmp_path):
+    rng = np.random.default_rng(7)
+    tab, sym = _rows8(rng, 300)
+    noise = rng.integers(0, 256, 4000, dtype=np.uint8).tobytes()
+    with open(str(tmp_path / "n.bin"), "wb") as f:
+        f.write(noise)
+    # any bit string is a valid arithmetic code of SOME symbols: product and restatement must name the same ones
+    got = _decode(product.coder, str(tmp_path / "n.bin"), tab, 300)
+    assert (got == _decode(coder_cpu.PyCoder, str(tmp_path / "n.bin"), tab, 300)).all()
+    assert _encode(product.coder, str(tmp_path / "b.bin"), tab, got)[:8] == noise[:8]
