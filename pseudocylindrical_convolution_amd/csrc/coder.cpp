@@ -57,6 +57,18 @@ class BitSink {
       bytes_[len_++] = (uint8_t)(acc_ >> fill_);
     }
   }
+  // the same for a caller that has reserve()d room for everything it is going to put: no capacity check, and
+  // the accumulator is emptied four bytes at a time (it holds up to 31 + 32 bits), big-endian like put()
+  inline void put_reserved(uint64_t v, int n) {
+    acc_ = (acc_ << n) | (v & ((1ull << n) - 1));
+    fill_ += n;
+    if (fill_ >= 32) {
+      fill_ -= 32;
+      const uint32_t w = __builtin_bswap32((uint32_t)(acc_ >> fill_));
+      memcpy(bytes_.data() + len_, &w, 4);
+      len_ += 4;
+    }
+  }
   void put_run(int bit, uint64_t count) {
     const uint64_t pattern = bit ? 0xffffffffull : 0;
     while (count > 0) {
@@ -66,7 +78,7 @@ class BitSink {
     }
   }
   void pad_to_byte() {
-    if (fill_ != 0) put(0, 8 - fill_);
+    put(0, (8 - fill_ % 8) % 8);  // (put() also empties the whole bytes put_reserved() may have left)
   }
   const uint8_t *data() const { return bytes_.data(); }
   size_t size() const { return len_; }
@@ -413,13 +425,15 @@ int pconv_coder_encodes(pconv_coder *c, const int32_t *table, int ncode, const i
       const int agree = clz32((uint32_t)((low ^ high) & kMask));
       if (agree > 0) {
         const uint32_t top = (uint32_t)(low >> (kStateBits - agree));
-        const int firstbit = (top >> (agree - 1)) & 1;
-        c->sink.put(firstbit, 1);
-        if (pending) {
+        if (__builtin_expect(pending == 0, 1)) {
+          c->sink.put_reserved(top, agree);  // (the first bit and the rest in one piece)
+        } else {
+          const int firstbit = (top >> (agree - 1)) & 1;
+          c->sink.put(firstbit, 1);
           c->sink.put_run(firstbit ^ 1, pending);
           pending = 0;
+          if (agree > 1) c->sink.put(top & ((1u << (agree - 1)) - 1), agree - 1);
         }
-        if (agree > 1) c->sink.put(top & ((1u << (agree - 1)) - 1), agree - 1);
         low = (low << agree) & kMask;
         high = ((high << agree) & kMask) | ((1ull << agree) - 1);
       }
