@@ -183,16 +183,17 @@ class ConvProbe(object):
     def summarise(self):
         torch.cuda.synchronize()
         per = {}
-        for kernel, label, flops, e0, e1 in self.records:
+        for kernel, label, flops, e0, e1, *rest in self.records:
             d = per.setdefault(kernel, {"flops": 0.0, "seconds": 0.0, "launches": 0, "classes": {}})
             t = e0.elapsed_time(e1) * 1e-3
             d["flops"] += flops
             d["seconds"] += t
             d["launches"] += 1
-            c = d["classes"].setdefault(label, [0.0, 0.0, 0])
+            c = d["classes"].setdefault(label, [0.0, 0.0, 0, 0.0])
             c[0] += flops
             c[1] += t
             c[2] += 1
+            c[3] += rest[0] if rest else 0.0   # algorithmic HBM bytes (tile-conv / GDN records)
         return per
 
 
@@ -467,7 +468,7 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         per_kernel = probe.summarise() if probe is not None else {}
         roof, table = None, []
         for kernel, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]["seconds"]):
-            for label, (fl, tt, n) in sorted(d["classes"].items(), key=lambda kv: -kv[1][1]):
+            for label, (fl, tt, n, nbytes) in sorted(d["classes"].items(), key=lambda kv: -kv[1][1]):
                 # fl = direct-convolution flops (2 Cin k^2 Cout per valid output pixel); a Winograd launch
                 # executes 1 / 2.25 of them: `achieved` / `frac` are executed matrix-core flops (<= peak)
                 gain = winograd_gain(kernel)
@@ -476,6 +477,12 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
                        "frac": round(fl / gain / tt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
                 if gain != 1.0:
                     row["direct_equivalent"] = round(fl / tt / 1e12, 2)
+                if nbytes:
+                    # the same launches against the HBM roof: input + output (+ residual / gate) once each.  The
+                    # 1x1 / GDN layers move 1.1-3 KB per pixel for 37-74 KFLOP: both roofs are about as far away
+                    row["hbm_achieved"] = round(nbytes / tt / 1e9, 1)
+                    row["hbm_frac"] = round(nbytes / tt / 1e9 / HBM_PEAK_GBS, 4)
+                    row["flop_per_byte"] = round(fl / gain / nbytes, 1)
                 table.append(row)
         if per_kernel:
             kernel = max(per_kernel, key=lambda k: per_kernel[k]["seconds"])

@@ -1225,8 +1225,10 @@ def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=N
          1 if inverse else 0, _ptr(col_limit), int(npart), _ptr(residual), ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
+        # (+ algorithmic HBM bytes: x in, y out, the residual: each once)
         probe.records.append((conv_kernel_name(ch, 1, 1, True, cin=ch, pixels=tn * h * w), "GDN %d w%d" % (ch, w),
-                              2.0 * ch * ch * tn * h * w * _VALID_FRACTION, e0, e1))
+                              2.0 * ch * ch * tn * h * w * _VALID_FRACTION, e0, e1,
+                              4.0 * ch * tn * h * w * _VALID_FRACTION * (3 if residual is not None else 2)))
     return out
 
 
@@ -1296,5 +1298,7 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
         flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
         kernel = "wino42_conv3x3_kernel" if wino42 else ("wino_conv3x3_kernel" if wino else
                                                          conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w))
-        probe.records.append((kernel, "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo), flops, e0, e1))
+        # algorithmic HBM bytes: the input once, the output once, residual / gate once each
+        nbytes = 4.0 * tn * _VALID_FRACTION * (cin * h * w + cout * ho * wo * (1 + (residual is not None) + (gate is not None)))
+        probe.records.append((kernel, "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo), flops, e0, e1, nbytes))
     return out

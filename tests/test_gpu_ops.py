@@ -471,6 +471,54 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
     assert torch.equal(resident[2][:1].cpu(), ref)   # tile 0 is live over its whole width
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(192, 96, (16, 34, 1026)), (96, 192, (16, 34, 1026)),
+                                            (192, 192, (16, 34, 1026)), (192, 768, (16, 18, 514)),
+                                            (192, 192, (16, 3, 70)), (96, 96, (2, 5, 7)), (96, 192, (128, 8, 256)),
+                                            (192, 192, (1, 64, 2048))])
+def test_streamed_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
+    """the streamed 1x1 kernel (persistent workgroups: eight matrix waves park a tile's accumulators in LDS, four
+    drain waves take it out under the next tile's matrix loop) issues the tiled kernel's MFMA chain and epilogue
+    operations per output: bit-identical results -- ragged right / lower edges, dead tiles, one tile per workgroup
+    and many, both cout block widths, residual, PReLU, trim, ring-buffer views, the GDN pair"""
+    tn, h, w = shape
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(tn, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / np.sqrt(cin))).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    sl = torch.rand(cout, generator=g).to(DEV)
+    res = torch.randn(tn, cout, h, w, generator=g).to(DEV)
+    limit = torch.tensor([w, (w * 7) // 8, w // 2 + 1, 64, 65, 1, w, 130] * 2, dtype=torch.int32).clamp(max=w).to(DEV)
+    owner = type("Owner", (), {})()
+
+    def variants():
+        out = [P().tile_conv2d(owner, x, wt, b, 1, sl, limit, 16, residual=res, trim=True, ring=2).clone(),
+               P().tile_conv2d(owner, x, wt, b, 1, sl, None, 0, residual=res).clone(),
+               P().tile_conv2d(owner, x, wt, None, 1, None, limit, 16).clone(),
+               P().tile_conv2d(owner, x, wt, b, 1, sl, limit, 16, trim=True).clone()]
+        if cin == cout:
+            gam = (torch.rand(cin, cin, generator=torch.Generator().manual_seed(5)) * 0.01 + torch.eye(cin) * 0.1).to(DEV)
+            beta = (torch.rand(cin, generator=torch.Generator().manual_seed(6)) + 0.5).to(DEV)
+            for inverse in (False, True):
+                out.append(P().tile_gdn(owner, x, gam, beta, inverse, limit, 16, res, 2).clone())
+                out.append(P().tile_gdn(owner, x, gam, beta, inverse, limit, 16, None, 0).clone())
+        return out
+
+    monkeypatch.setenv("PCONV_CONV1X1", "tiled")
+    tiled = variants()
+    monkeypatch.setenv("PCONV_CONV1X1", "stream")
+    streamed = variants()
+    # the tiled kernel with full tiles leaving in 16-byte quads through the stage memory
+    monkeypatch.setenv("PCONV_CONV1X1", "tiled")
+    monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "quads")
+    quads = variants()
+    monkeypatch.delenv("PCONV_CONV1X1")
+    monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
+    for name, other in (("streamed", streamed), ("quads", quads)):
+        for i, (a, r) in enumerate(zip(tiled, other)):
+            assert torch.isfinite(r).all()
+            assert torch.equal(a, r), "%s, variant %d: max abs diff %g" % (name, i, (a - r).abs().max().item())
+
+
 def test_timeit_prints_like_the_reference_timer(capsys):
     """`timeit=True` (last constructor argument of every op, base_opt.hpp:7-8, timer.h:32-44): events
     around the op's call, `<head> Elapsed time : <ms> ms` on stdout"""

@@ -21,14 +21,15 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-for (cin, cout, rows, cols, res) in ((96, 192, 32, 1024, True), (192, 192, 32, 1024, True), (192, 768, 32, 1024, False)):
-    x = torch.randn(16, cin, rows, cols, device=dev)
+for (cin, cout, rows, cols, res) in ((96, 192, 32, 1024, True), (192, 96, 34, 1026, False), (192, 192, 32, 1024, True), (192, 768, 32, 1024, False)):
+    TN = int(os.environ.get("PROBE_TN", "16"))   # 128: the codec's batched small-scale layers (8 frames)
+    x = torch.randn(TN, cin, rows, cols, device=dev)
     conv = torch.nn.Conv2d(cin, cout, 1).to(dev)
-    r = torch.randn(16, cout, rows, cols, device=dev) if res else None
+    r = torch.randn(TN, cout, rows, cols, device=dev) if res else None
     wd = PCONV.tile_widths(W16, 16, rows * 16, cols)
     lim = torch.from_numpy(wd.astype(np.int32)).to(dev)
     ms = timed(lambda: PCONV.tile_conv2d(conv, x, conv.weight, conv.bias, 1, None, lim, 16, residual=r, trim=res))
-    px = float(wd.sum()) * rows
+    px = float(wd.sum()) * rows * TN / 16
     byt = px * 4 * (cin + cout + (cout if res else 0))
     print("1x1 %d->%d w%d%s: %.3f ms  %.2f TB/s  %.1f TFLOP/s (valid columns)" % (
         cin, cout, cols, " +residual" if res else "", ms, byt / ms * 1e-9, 2.0 * cin * cout * px / ms * 1e-9))
