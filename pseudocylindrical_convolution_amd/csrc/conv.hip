@@ -41,6 +41,13 @@ constexpr int kTileCols = 64;
 #ifndef PCONV_KC1
 #define PCONV_KC1 16  // input channels per LDS stage of the 1x1 layers
 #endif
+// quads requested ahead of their turn in conv_epilogue_quads (4 registers each; 8 for the GDN with a residual)
+#ifndef PCONV_QUAD_AHEAD
+#define PCONV_QUAD_AHEAD 4
+#endif
+#ifndef PCONV_QUAD_AHEAD_GDN
+#define PCONV_QUAD_AHEAD_GDN 3
+#endif
 
 template <int ROWS, int KS, int S>
 struct Patch {
@@ -386,7 +393,7 @@ __device__ __forceinline__ void conv_epilogue_quads(f32x16 (&acc)[MT][1], const 
   // depend on what is parked) and waits in a register ring of D + 1 quads; the twelve quads of a tile are
   // straight-line code, a ring slot is a NAME (flat quad index % (D + 1)), never copied
   constexpr int NF = MT * NQR;                 // quads per lane and tile
-  constexpr int D = (SQ && RES) ? 3 : 4;
+  constexpr int D = (SQ && RES) ? PCONV_QUAD_AHEAD_GDN : PCONV_QUAD_AHEAD;
   QuadIn ring[D + 1];
   auto request = [&](auto fc) {
     constexpr int f = decltype(fc)::value, m = f / NQR, j = f % NQR;
@@ -596,6 +603,11 @@ __device__ __forceinline__ void conv_chunk_prologue(float (&a)[kAhead + 1][C::MT
 #define PCONV_1X1_EPI_ROWS 16
 #endif
 
+// cout rows per batch of the element-wise way out the ragged tiles of the quad kernels fall back to (few tiles:
+// small batches keep the fallback out of the kernel's register count)
+#ifndef PCONV_QUAD_FALLBACK_ROWS
+#define PCONV_QUAD_FALLBACK_ROWS 4
+#endif
 #ifdef PCONV_CONV_STAMP
 // profiling build: s_memtime of one workgroup per launch: [wave][entry, first chunk, end of the matrix loop, end,
 // s_memrealtime at entry (100 MHz), SIMD/CU id]
@@ -775,8 +787,8 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
         conv_epilogue_quads<MT, WM, WN, SQ, WAY == 4>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, wo, wm, wn, l31, half,
                                                       lds + 2 * C::BM, lds, lds + C::BM, tid);
       else
-        conv_epilogue_pipe<MT, NT, WN, SQ, WAY == 4>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn,
-                                                    l31, half, lds, lds + C::BM);
+        conv_epilogue<MT, NT, WN, PCONV_QUAD_FALLBACK_ROWS>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half,
+                                                           lds, lds + C::BM);
     } else
       conv_epilogue_pipe<MT, NT, WN, SQ, WAY == 2>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn,
                                                   l31, half, lds, lds + C::BM);
@@ -1675,10 +1687,11 @@ inline bool pipe_way_out() {
   const char *env = getenv("PCONV_CONV1X1_WAYOUT");  // (read per call: the parity test switches it)
   return !(env && env[0] == 'b');
 }
-// PCONV_CONV1X1_WAYOUT=quads: full tiles leave through the stage memory in 16-byte quads (conv_epilogue_quads)
+// default: full tiles leave through the stage memory in 16-byte quads (conv_epilogue_quads);
+// PCONV_CONV1X1_WAYOUT=pipe / batch: the element-wise ways out (A/B measurements, parity tests)
 inline bool quad_way_out() {
   const char *env = getenv("PCONV_CONV1X1_WAYOUT");
-  return env && env[0] == 'q';
+  return !(env && (env[0] == 'p' || env[0] == 'b'));
 }
 
 // (cout, cin, k, k) -> [k_pad][cout_pad], k = (ci*KS + kh)*KS + kw, zero padded

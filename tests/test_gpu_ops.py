@@ -452,12 +452,16 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
         return out
 
     monkeypatch.setenv("PCONV_CONV1X1", "tiled")
-    tiled = variants()
-    # the tiled kernel's two ways out -- rows requested a batch ahead as straight-line code (default, for
-    # layers with a residual and the GDN pair) and conv_epilogue's whole-tile batches: identical bits
+    tiled = variants()   # (the default way out: 16-byte quads through the stage memory for full tiles)
+    # the tiled kernel's element-wise ways out -- rows requested a batch ahead as straight-line code ("pipe") and
+    # conv_epilogue's whole-tile batches ("batch"): identical bits
     monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "batch")
     batched = variants()
+    monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "pipe")
+    piped = variants()
     monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
+    for i, (a, r) in enumerate(zip(tiled, piped)):
+        assert torch.equal(a, r), "pipelined way out, variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
     for i, (a, r) in enumerate(zip(tiled, batched)):
         assert torch.equal(a, r), "way out, variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
     monkeypatch.setenv("PCONV_CONV1X1", "resident")
@@ -504,15 +508,14 @@ def test_streamed_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
         return out
 
     monkeypatch.setenv("PCONV_CONV1X1", "tiled")
+    monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "pipe")   # the element-wise, pipelined way out
     tiled = variants()
+    monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
     monkeypatch.setenv("PCONV_CONV1X1", "stream")
     streamed = variants()
-    # the tiled kernel with full tiles leaving in 16-byte quads through the stage memory
-    monkeypatch.setenv("PCONV_CONV1X1", "tiled")
-    monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "quads")
-    quads = variants()
+    # the default: the tiled kernel with full tiles leaving in 16-byte quads through the stage memory
     monkeypatch.delenv("PCONV_CONV1X1")
-    monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
+    quads = variants()
     for name, other in (("streamed", streamed), ("quads", quads)):
         for i, (a, r) in enumerate(zip(tiled, other)):
             assert torch.isfinite(r).all()
