@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
                                                                                           cout, ho, wo, wm, wn, l31, half, lds, lds + C::BM);
     } else if constexpr (WAY >= 3) {
       // quads through the stage memory for full tiles, the pipelined element-wise way out for the ragged ones
-      static_assert(WAY < 3 || (KS == 1 && S == 1 && MT == 3 && NT == 1 && kThreads == 512), "quad way out: 1x1 stride-1 tiles of eight waves");
+      static_assert(WAY < 3 || (MT == 3 && NT == 1 && kThreads == 512 && (!SQ || (KS == 1 && S == 1))), "quad way out: 96 couts x 32 pixels per wave, eight waves");
       static_assert(WAY < 3 || (2 * C::BM + 32 * WM * 32 * WN) <= 2 * C::STAGE, "a round fits the stage memory behind the tables");
       if (c0 + kTileCols <= wo && r0 + kTileRows <= ho && cout0 + C::BM <= cout)
         conv_epilogue_quads<MT, WM, WN, SQ, WAY == 4>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, wo, wm, wn, l31, half,
@@ -1835,6 +1835,12 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
     rc = launch_conv<1, 1, 1, 4, KS, S, KC>(ARGS);
   if (k == 3 && stride == 1) {
     BY_TILE(3, 1, 4)
+  } else if (k == 3 && stride == 2 && cout > 32 && !gate && !d2w && act != 4 && quad_way_out()) {
+    // (the stride-2 3x3 layers of the Down blocks: the same workgroup tiles, the same quad way out)
+    if (cout > 96)
+      rc = residual ? launch_conv<3, 1, 2, 4, 3, 2, 4, false, 4>(ARGS) : launch_conv<3, 1, 2, 4, 3, 2, 4, false, 3>(ARGS);
+    else
+      rc = residual ? launch_conv<3, 1, 1, 8, 3, 2, 4, false, 4>(ARGS) : launch_conv<3, 1, 1, 8, 3, 2, 4, false, 3>(ARGS);
   } else if (k == 3 && stride == 2) {
     BY_TILE(3, 2, 4)
   } else if (k == 1 && stride == 1 && !gate && !d2w && act != 4 && use_resident_1x1(cin, cout, tn, h, w)) {

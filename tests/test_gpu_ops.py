@@ -522,6 +522,38 @@ def test_streamed_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
             assert torch.equal(a, r), "%s, variant %d: max abs diff %g" % (name, i, (a - r).abs().max().item())
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(192, 192, (16, 33, 1025)), (192, 96, (16, 17, 257)), (3, 192, (2, 65, 131))])
+def test_stride2_3x3_quad_way_out_equals_elementwise(cin, cout, shape, monkeypatch):
+    """the stride-2 3x3 layers (Down blocks) share the 1x1 layers' workgroup tiles and their quad way out through
+    the stage memory: identical bits to the element-wise way out (PCONV_CONV1X1_WAYOUT=batch), with PReLU, residual,
+    trim, dead tiles, ragged edges and ring-buffer outputs"""
+    tn, h, w = shape
+    g = torch.Generator().manual_seed(59)
+    x = torch.randn(tn, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / np.sqrt(cin * 9))).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    sl = torch.rand(cout, generator=g).to(DEV)
+    ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    res = torch.randn(tn, cout, ho, wo, generator=g).to(DEV)
+    limit = torch.tensor([wo, (wo * 7) // 8, wo // 2 + 1, 64, 65, 1, wo, 130] * 2, dtype=torch.int32).clamp(max=wo)[:16].to(DEV)
+    owner = type("Owner", (), {})()
+
+    def variants():
+        return [P().tile_conv2d(owner, x, wt, b, 2, sl, limit, 16, residual=res, trim=True, ring=1).clone(),
+                P().tile_conv2d(owner, x, wt, b, 2, sl, None, 0).clone(),
+                P().tile_conv2d(owner, x, wt, None, 2, None, limit, 16, residual=res).clone()]
+
+    quads = variants()
+    monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "batch")
+    plain = variants()
+    monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
+    for i, (a, r) in enumerate(zip(plain, quads)):
+        assert torch.isfinite(r).all()
+        assert torch.equal(a, r), "variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
+    ref = O.conv2d_chain(x[:1].cpu(), wt.cpu(), None, 2, None)
+    assert torch.equal(P().tile_conv2d(owner, x[:1], wt, None, 2, None, None, 0).cpu(), ref)
+
+
 def test_timeit_prints_like_the_reference_timer(capsys):
     """`timeit=True` (last constructor argument of every op, base_opt.hpp:7-8, timer.h:32-44): events
     around the op's call, `<head> Elapsed time : <ms> ms` on stdout"""
