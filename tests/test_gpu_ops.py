@@ -479,10 +479,10 @@ def test_resident_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
                                             (192, 192, (16, 34, 1026)), (192, 768, (16, 18, 514)),
                                             (192, 192, (16, 3, 70)), (96, 96, (2, 5, 7)), (96, 192, (128, 8, 256)),
                                             (192, 192, (1, 64, 2048))])
-def test_streamed_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
-    """the streamed 1x1 kernel (persistent workgroups: eight matrix waves park a tile's accumulators in LDS, four
-    drain waves take it out under the next tile's matrix loop) issues the tiled kernel's MFMA chain and epilogue
-    operations per output: bit-identical results -- ragged right / lower edges, dead tiles, one tile per workgroup
+def test_quad_way_out_equals_elementwise_way_out(cin, cout, shape, monkeypatch):
+    """full tiles of the 1x1 / GDN layers leave through the stage memory in 16-byte quads (conv_epilogue_quads, the
+    default): the same epilogue operations per output as the element-wise, pipelined way out (PCONV_CONV1X1_WAYOUT=
+    pipe) -- identical bits: ragged right / lower edges (element-wise fallback), dead tiles, one tile per workgroup
     and many, both cout block widths, residual, PReLU, trim, ring-buffer views, the GDN pair"""
     tn, h, w = shape
     g = torch.Generator().manual_seed(53)
@@ -507,19 +507,13 @@ def test_streamed_1x1_equals_tiled_kernel(cin, cout, shape, monkeypatch):
                 out.append(P().tile_gdn(owner, x, gam, beta, inverse, limit, 16, None, 0).clone())
         return out
 
-    monkeypatch.setenv("PCONV_CONV1X1", "tiled")
     monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "pipe")   # the element-wise, pipelined way out
-    tiled = variants()
+    piped = variants()
     monkeypatch.delenv("PCONV_CONV1X1_WAYOUT")
-    monkeypatch.setenv("PCONV_CONV1X1", "stream")
-    streamed = variants()
-    # the default: the tiled kernel with full tiles leaving in 16-byte quads through the stage memory
-    monkeypatch.delenv("PCONV_CONV1X1")
-    quads = variants()
-    for name, other in (("streamed", streamed), ("quads", quads)):
-        for i, (a, r) in enumerate(zip(tiled, other)):
-            assert torch.isfinite(r).all()
-            assert torch.equal(a, r), "%s, variant %d: max abs diff %g" % (name, i, (a - r).abs().max().item())
+    quads = variants()                                    # the default
+    for i, (a, r) in enumerate(zip(piped, quads)):
+        assert torch.isfinite(r).all()
+        assert torch.equal(a, r), "variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(192, 192, (16, 33, 1025)), (192, 96, (16, 17, 257)), (3, 192, (2, 65, 131))])
