@@ -1118,6 +1118,174 @@ inline bool use_resident_1x1(int cin, int cout, int tn, int h, int w) {
   return false;
 }
 
+// ---- 3x3 stride-1 convolution with <= 16 couts on v_mfma_f32_16x16x4_f32 --------------------
+// The codec's last layer (model_zoo_v2.py:296-303: 192 -> 12 channels, then Dtow to the 3 image planes) is the one
+// place where the 32-cout granule of v_mfma_f32_32x32x2_f32 hurts: 12 of 32 matrix rows do work (the 32-cout tile
+// of conv_mfma_kernel runs it at 0.28 of the peak in useful flops, 0.375 is its ceiling).  The 16 x 16 x 4
+// instruction has half the rows at the same rate -- 12 of 16 busy -- and accumulates its four products as one
+// k-ascending fmaf chain just like the 32 x 32 x 2 one (tools/mfma16_chain_probe.hip: 0 of 256 outputs differ), so
+// the numerics contract (one k-ascending chain per output) holds bit for bit.
+//   workgroup = 8 waves = 8 output rows x 64 columns, all 16 couts; wave = one row = 4 column groups of 16;
+//   per chunk of 4 input channels (36 reduction entries = 9 instructions of 4): patch 4 x 10 x 66 and weights
+//   36 x 16 by LDS-DMA, double buffered; lane (r = l % 16, q = l / 16) feeds entry 4 s + q: A = W[4 s + q][r],
+//   B = patch element of entry 4 s + q at the wave's row, column 16 n + r; D: couts 4 q .. 4 q + 3 of column r.
+// With the depth-to-width store a lane holds exactly the 2 x 2 sub-pixels of output channel q: two 8-byte stores.
+// Takes bias, PReLU, trim / dead tiles, the Dtow store; no residual / gate / sigmoid.
+template <int KS>
+__global__ __launch_bounds__(512, 2) void conv_small_kernel(const float *__restrict__ in, const float *__restrict__ wp,
+                                                            float *__restrict__ out, int cin, int h, int w, int cout,
+                                                            int cout_pad, int ho, int wo, int tiles_r, int tiles_c,
+                                                            ConvView vin, ConvView vout, ConvEpilogue ep) {
+  static_assert(KS == 3, "small-cout kernel: 3x3 stride 1");
+  constexpr int KC = 4, ROWS = 8, PR = ROWS + KS - 1, PC = kTileCols + KS - 1, KK = KC * KS * KS, NS = KK / 4;
+  constexpr int XSZ = KC * PR * PC, WSZ = KK * 16, STAGE = XSZ + WSZ, kThreads = 512;
+  constexpr int XLD = (XSZ + kThreads - 1) / kThreads;
+  static_assert(KK % 4 == 0 && (2 * STAGE) * 4 + 256 < 65536, "immediate offsets reach both buffers");
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  int b = blockIdx.x;
+  const int trx = b % tiles_r;
+  b /= tiles_r;
+  const int tcx = b % tiles_c;
+  const int t = b / tiles_c;
+  const int r0 = trx * ROWS, c0 = tcx * kTileCols;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  float *outp = out + (size_t)t * vout.ts;
+  if (ep.col_limit && c0 >= ep.col_limit[t % ep.npart]) {
+    conv_zero_tile<16, ROWS, kThreads>(outp, vout, ep.d2w, 0, cout, r0, c0, ho, wo, tid);
+    return;
+  }
+  const float *inp = in + (size_t)t * vin.ts;
+  const int nchunk = (cin + KC - 1) / KC, tail = cin % KC;
+  unsigned xoffs[XLD];
+#pragma unroll
+  for (int j = 0; j < XLD; j++) {
+    int e = tid + j * kThreads;
+    e = e < XSZ ? e : 0;
+    const int pc = e % PC, pr = (e / PC) % PR, ci = e / (PC * PR);
+    int ir = r0 + pr, ic = c0 + pc;
+    ir = ir < h ? ir : h - 1;
+    ic = ic < w ? ic : w - 1;
+    xoffs[j] = (unsigned)((ci * vin.cs + (long long)ir * vin.rs + ic) * 4);
+  }
+  // weights: rows of the packed [k][cout_pad] slab, the first 16 couts: 4 float4 per reduction entry
+  const int we4 = tid < KK * 4 ? tid : 0;
+  const unsigned woff = (unsigned)(((we4 >> 2) * cout_pad + (we4 & 3) * 4) * 4);
+  const size_t xstep = (size_t)KC * vin.cs, wstep = (size_t)KK * cout_pad;
+  auto stage = [&](int chunk, int buf) {
+    if (chunk >= nchunk) return;
+    float *xs = lds + buf * STAGE;
+    const float *xb = inp + chunk * xstep;
+    const bool ragged = tail != 0 && chunk == nchunk - 1;
+#pragma unroll
+    for (int j = 0; j < XLD; j++) {
+      const int e = tid + j * kThreads;
+      if (e < XSZ) {
+        unsigned off = xoffs[j];
+        if (ragged) {
+          // channels past cin: the last real one again -- their weight rows are zero: + 0 to the chain
+          const int ci = e / (PC * PR);
+          if (ci >= tail) off -= (unsigned)((ci - tail + 1) * vin.cs * 4);
+        }
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)((glb_bytes_t *)xb + off), (lds_ptr_t *)(xs + j * kThreads + wave * 64), 4, 0,
+                                         0);
+      }
+    }
+    if (tid < KK * 4) {
+      unsigned off = woff;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)((glb_bytes_t *)(wp + chunk * wstep) + off),
+                                       (lds_ptr_t *)(xs + XSZ + wave * 64 * 4), 16, 0, 0);
+    }
+  };
+  // the lane's patch element of entry 4 s + q, at the wave's row, column r (column group n: + 16 n floats)
+  int boff[NS];
+#pragma unroll
+  for (int s4 = 0; s4 < NS; s4++) {
+    const int k = 4 * s4 + q;
+    boff[s4] = (k / (KS * KS)) * PR * PC + ((k / KS) % KS) * PC + k % KS + wave * PC + r;
+  }
+  const int aoff = XSZ + q * 16 + r;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  stage(0, 0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; chunk++) {
+    const int buf = chunk & 1;
+    stage(chunk + 1, buf ^ 1);
+    const float *xs = lds + buf * STAGE;
+#pragma unroll
+    for (int s4 = 0; s4 < NS; s4++) {
+      const float av = xs[aoff + s4 * 64];
+      float bv[4];
+#pragma unroll
+      for (int n = 0; n < 4; n++) bv[n] = xs[boff[s4] + 16 * n];
+#pragma unroll
+      for (int n = 0; n < 4; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- way out: lane (r, q) holds couts 4 q .. 4 q + 3 of row `wave`, columns 16 n + r ----
+  const int orow = r0 + wave;
+  if (orow >= ho) return;
+  const int act = ep.act;
+  const int trim_at = (ep.trim && ep.col_limit) ? ep.col_limit[t % ep.npart] : wo;
+  float bco[4], sl[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int co = 4 * q + i < cout ? 4 * q + i : cout - 1;
+    bco[i] = ep.bias ? ep.bias[co] : 0.f;
+    sl[i] = act == 1 ? ep.slope[co] : 1.f;
+  }
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int ocol = c0 + 16 * n + r;
+    if (ocol >= wo) continue;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      v[i] = acc[n][i] + bco[i];
+      if (act == 1 && v[i] < 0) v[i] = v[i] * sl[i];
+    }
+    if (ep.d2w) {
+      // cout 4 q + 2 sy + sx -> channel q, row 2 orow + sy, column 2 ocol + sx
+      if (4 * q + 3 < cout) {
+#pragma unroll
+        for (int sy = 0; sy < 2; sy++)
+          *reinterpret_cast<float2 *>(outp + (size_t)q * vout.cs + (size_t)(2 * orow + sy) * vout.rs + 2 * ocol) =
+              make_float2(v[2 * sy], v[2 * sy + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (4 * q + i < cout) outp[(size_t)(4 * q + i) * vout.cs + (size_t)orow * vout.rs + ocol] = ocol >= trim_at ? 0.f : v[i];
+    }
+  }
+}
+
+// PCONV_CONV_SMALL=0: the 32-cout tile of conv_mfma_kernel keeps the layers with <= 16 couts (A/B, parity test)
+inline bool use_small_cout() {
+  const char *env = getenv("PCONV_CONV_SMALL");  // (read per call: the parity test switches it)
+  return !(env && env[0] == '0');
+}
+
+int launch_conv_small(const float *in, const float *wp, float *out, int tn, int cin, int h, int w, int cout, int cout_pad,
+                      int ho, int wo, const ConvView &vin, const ConvView &vout, const ConvEpilogue &ep, hipStream_t stream) {
+  const int tiles_r = (ho + 7) / 8, tiles_c = (wo + kTileCols - 1) / kTileCols;
+  const long long grid = (long long)tn * tiles_r * tiles_c;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    pconv_set_error("conv2d: grid %lld out of range", grid);
+    return PCONV_EINVAL;
+  }
+  hipLaunchKernelGGL(conv_small_kernel<3>, dim3((unsigned)grid), dim3(512), 0, stream, in, wp, out, cin, h, w, cout, cout_pad,
+                     ho, wo, tiles_r, tiles_c, vin, vout, ep);
+  return PCONV_OK;
+}
+
 #ifdef PCONV_CONV_STAMP
 extern "C" int pconv_conv_read_stamps(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_stamps), sizeof(conv_stamps)) == hipSuccess ? 0 : 1;
@@ -1275,7 +1443,9 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
     rc = launch_conv<3, 1, 1, 8, KS, S, KC>(ARGS);                 \
   else                                                             \
     rc = launch_conv<1, 1, 1, 4, KS, S, KC>(ARGS);
-  if (k == 3 && stride == 1) {
+  if (k == 3 && stride == 1 && cout <= 16 && !residual && !gate && act != 4 && (!d2w || cout % 4 == 0) && use_small_cout()) {
+    rc = launch_conv_small(in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, vin, vout, ep, s);
+  } else if (k == 3 && stride == 1) {
     BY_TILE(3, 1, 4)
   } else if (k == 3 && stride == 2 && cout > 32 && !gate && !d2w && act != 4 && quad_way_out()) {
     // (the stride-2 3x3 layers of the Down blocks: the same workgroup tiles, the same quad way out)

@@ -548,6 +548,44 @@ def test_stride2_3x3_quad_way_out_equals_elementwise(cin, cout, shape, monkeypat
     assert torch.equal(P().tile_conv2d(owner, x[:1], wt, None, 2, None, None, 0).cpu(), ref)
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(192, 12, (16, 18, 130)), (24, 16, (2, 11, 70)), (6, 3, (3, 5, 9)),
+                                            (192, 12, (1, 66, 2050))])
+def test_small_cout_3x3_kernel(cin, cout, shape, monkeypatch):
+    """3x3 stride-1 layers with <= 16 couts (the codec's 192 -> 12 output layer) run on v_mfma_f32_16x16x4_f32 tiles
+    of 16 couts: the same k-ascending fmaf chain per output as the 32-cout tile of conv_mfma_kernel
+    (PCONV_CONV_SMALL=0) and as the oracle -- bias, PReLU, trim, dead tiles, ragged edges and channel counts, the
+    depth-to-width store, ring-buffer outputs"""
+    tn, h, w = shape
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(tn, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / np.sqrt(cin * 9))).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    sl = torch.rand(cout, generator=g).to(DEV)
+    wo = w - 2
+    npart = 16 if tn % 16 == 0 else 1
+    limit = torch.tensor([wo, (wo * 7) // 8, wo // 2 + 1, 64, 65, 1, wo, 130] * 2, dtype=torch.int32).clamp(max=wo)[:npart].to(DEV)
+    owner = type("Owner", (), {})()
+
+    def variants():
+        out = [P().tile_conv2d(owner, x, wt, b, 1, sl, limit, npart, trim=True, ring=1).clone(),
+               P().tile_conv2d(owner, x, wt, None, 1, None, None, 0).clone(),
+               P().tile_conv2d(owner, x, wt, b, 1, None, limit, npart).clone()]
+        if cout % 4 == 0:
+            out.append(P().tile_conv2d(owner, x, wt, b, 1, None, limit, npart, d2w=True).clone())
+            out.append(P().tile_conv2d(owner, x, wt, b, 1, sl, None, 0, d2w=True, ring=2).clone())
+        return out
+
+    small = variants()
+    monkeypatch.setenv("PCONV_CONV_SMALL", "0")
+    tiled = variants()
+    monkeypatch.delenv("PCONV_CONV_SMALL")
+    for i, (a, r) in enumerate(zip(tiled, small)):
+        assert torch.isfinite(r).all()
+        assert torch.equal(a, r), "variant %d: max abs diff %g" % (i, (a - r).abs().max().item())
+    ref = O.conv2d_chain(x[:1].cpu(), wt.cpu(), b.cpu(), 1, sl.cpu())
+    assert torch.equal(P().tile_conv2d(owner, x[:1], wt, b, 1, sl, None, 0).cpu(), ref)
+
+
 def test_timeit_prints_like_the_reference_timer(capsys):
     """`timeit=True` (last constructor argument of every op, base_opt.hpp:7-8, timer.h:32-44): events
     around the op's call, `<head> Elapsed time : <ms> ms` on stdout"""
