@@ -1163,7 +1163,8 @@ def conv_kernel_name(cout, k, stride, squared=False, cin=0, pixels=0):
             (cin + 15) // 16 * 16 * (192 if cout > 96 else 96) * 4 <= 150 * 1024:
         return "conv1x1_rb_kernel<%d, %s>" % (2 if cout > 96 else 1, sq)
     if k == 3 and stride == 1 and cout <= 16 and os.environ.get("PCONV_CONV_SMALL", "1") != "0":
-        return "conv_small_kernel<3>"   # (16-cout tiles on v_mfma_f32_16x16x4_f32: the 12-channel output layer)
+        # (16-cout tiles on v_mfma_f32_16x16x4_f32: the 12-channel output layer)
+        return "conv_small_kernel<3, 4>"
     mt, nt, wm, wn = (3, 1, 2, 4) if cout > 96 else ((3, 1, 1, 8) if cout > 32 else (1, 1, 1, 4))
     return "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>" % (mt, nt, wm, wn, k, stride, 16 if k == 1 else 4, sq)
 
