@@ -1505,6 +1505,12 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
       rc = launch_conv<1, 1, 1, 4, 1, 1, PCONV_KC1, false, 2>(ARGS);
   } else if (k == 1 && stride == 1) {
     BY_TILE(1, 1, PCONV_KC1)
+  } else if (cout > 32 && !gate && !d2w && act != 4 && quad_way_out()) {
+    // (1x1 stride 2, the shortcuts of the Down blocks: same tiles, same quad way out)
+    if (cout > 96)
+      rc = residual ? launch_conv<3, 1, 2, 4, 1, 2, PCONV_KC1, false, 4>(ARGS) : launch_conv<3, 1, 2, 4, 1, 2, PCONV_KC1, false, 3>(ARGS);
+    else
+      rc = residual ? launch_conv<3, 1, 1, 8, 1, 2, PCONV_KC1, false, 4>(ARGS) : launch_conv<3, 1, 1, 8, 1, 2, PCONV_KC1, false, 3>(ARGS);
   } else {
     BY_TILE(1, 2, PCONV_KC1)
   }

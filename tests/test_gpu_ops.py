@@ -517,7 +517,7 @@ def test_quad_way_out_equals_elementwise_way_out(cin, cout, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(192, 192, (16, 33, 1025)), (192, 96, (16, 17, 257)), (3, 192, (2, 65, 131))])
-def test_stride2_3x3_quad_way_out_equals_elementwise(cin, cout, shape, monkeypatch):
+def test_stride2_quad_way_out_equals_elementwise(cin, cout, shape, monkeypatch):
     """the stride-2 3x3 layers (Down blocks) share the 1x1 layers' workgroup tiles and their quad way out through
     the stage memory: identical bits to the element-wise way out (PCONV_CONV1X1_WAYOUT=batch), with PReLU, residual,
     trim, dead tiles, ragged edges and ring-buffer outputs"""
@@ -532,10 +532,15 @@ def test_stride2_3x3_quad_way_out_equals_elementwise(cin, cout, shape, monkeypat
     limit = torch.tensor([wo, (wo * 7) // 8, wo // 2 + 1, 64, 65, 1, wo, 130] * 2, dtype=torch.int32).clamp(max=wo)[:16].to(DEV)
     owner = type("Owner", (), {})()
 
+    w1 = wt[:, :, 1:2, 1:2].contiguous()                 # and the 1x1 stride-2 shortcut of the same blocks
+    x1 = x[:, :, :2 * ho - 1, :2 * wo - 1].contiguous()  # (same output geometry)
+
     def variants():
         return [P().tile_conv2d(owner, x, wt, b, 2, sl, limit, 16, residual=res, trim=True, ring=1).clone(),
                 P().tile_conv2d(owner, x, wt, b, 2, sl, None, 0).clone(),
-                P().tile_conv2d(owner, x, wt, None, 2, None, limit, 16, residual=res).clone()]
+                P().tile_conv2d(owner, x, wt, None, 2, None, limit, 16, residual=res).clone(),
+                P().tile_conv2d(owner, x1, w1, b, 2, sl, limit, 16, residual=res, trim=True, ring=1).clone(),
+                P().tile_conv2d(owner, x1, w1, None, 2, None, None, 0).clone()]
 
     quads = variants()
     monkeypatch.setenv("PCONV_CONV1X1_WAYOUT", "batch")
