@@ -457,6 +457,49 @@ __device__ __forceinline__ void conv_epilogue_quads(f32x16 (&acc)[MT][1], const 
   }
 }
 
+// The same for the depth-to-width store (Dtow fused: cout 4c' + 2sy + sx at (row, col) -> channel c' at
+// (2 row + sy, 2 col + sx); bias / PReLU only): four consecutive output floats are two neighbouring pixels of two
+// neighbouring couts, i.e. two 8-byte reads from neighbouring rows of the parked round, interleaved; the 64 lanes of
+// a wave then write 1 KB of one output row.
+template <int MT, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_quads_d2w(f32x16 (&acc)[MT][1], const ConvEpilogue &ep, float *out_t,
+                                                        const ConvView &vout, int r0, int c0, int cout0, int wm, int wn,
+                                                        int l31, int half, float *park, const float *bias_s,
+                                                        const float *slope_s, int tid) {
+  constexpr int PX = 32 * WN, PROW = PX / 2, RROWS = 32 * WM, NQR = (RROWS / 2) * PROW / 512, PSTEP = 512 / PROW;
+  static_assert(WM * WN == 8 && (RROWS / 2) * PROW % 512 == 0 && 16 % PSTEP == 0, "eight waves, whole quads per lane and round");
+  const bool prelu = ep.act == 1;
+  const int pair0 = tid / PROW, px = (tid % PROW) * 2;          // row pair inside the round, first pixel
+  const int orow = r0 + px / kTileCols, ocol = c0 + px % kTileCols;
+  // row pair j * PSTEP + pair0 of round m = couts K(m, j) + 2 pair0, + 1 of the block, K uniform and even
+  auto krow = [](int m, int j) { return ((2 * j * PSTEP) / 32 * MT + m) * 32 + (2 * j * PSTEP) % 32; };
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) park[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PX + wn * 32 + l31] = acc[m][0][r];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NQR; j++) {
+      const int cb = krow(m, j) + 2 * pair0;  // even cout inside the block: sx = 0; cb + 1: sx = 1
+      const float2 a = *reinterpret_cast<const float2 *>(park + (2 * (j * PSTEP + pair0)) * PX + px);
+      const float2 b = *reinterpret_cast<const float2 *>(park + (2 * (j * PSTEP + pair0) + 1) * PX + px);
+      const float ba = bias_s[cb], bb = bias_s[cb + 1];
+      float v[4] = {a.x + ba, b.x + bb, a.y + ba, b.y + bb};
+      if (prelu) {
+        const float sa = slope_s[cb], sb = slope_s[cb + 1];
+        if (v[0] < 0) v[0] = v[0] * sa;
+        if (v[1] < 0) v[1] = v[1] * sb;
+        if (v[2] < 0) v[2] = v[2] * sa;
+        if (v[3] < 0) v[3] = v[3] * sb;
+      }
+      const int co = cout0 + cb;
+      float *dst = out_t + (size_t)(co >> 2) * vout.cs + (size_t)(2 * orow + ((co >> 1) & 1)) * vout.rs + 2 * ocol;
+      *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (m + 1 < MT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
 // LDS-DMA of one chunk (input patch + weight slab): XLD patch dwords, then WLD weight float4s per
 // thread, all issued at the head of the previous chunk's matrix loop.  (Issuing them one piece every
 // second k-pair instead -- so that the ~30 KB do not come back in one burst -- measured 1.5 % slower.)
@@ -779,10 +822,19 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
     if constexpr (WAY == 0) {
       conv_epilogue<MT, NT, WN, (KS == 1 && S == 1 && MT == 3) ? PCONV_1X1_EPI_ROWS : 16>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0,
                                                                                           cout, ho, wo, wm, wn, l31, half, lds, lds + C::BM);
+    } else if constexpr (WAY == 5) {
+      // depth-to-width store in quads for full tiles
+      static_assert(WAY != 5 || (MT == 3 && NT == 1 && kThreads == 512 && !SQ), "d2w quad way out: 96 couts x 32 pixels per wave");
+      static_assert(WAY != 5 || (2 * C::BM + 32 * WM * 32 * WN) <= 2 * C::STAGE, "a round fits the stage memory behind the tables");
+      if (c0 + kTileCols <= wo && r0 + kTileRows <= ho && cout0 + C::BM <= cout)
+        conv_epilogue_quads_d2w<MT, WM, WN>(acc, ep, outp, vout, r0, c0, cout0, wm, wn, l31, half, lds + 2 * C::BM, lds, lds + C::BM, tid);
+      else
+        conv_epilogue<MT, NT, WN, PCONV_QUAD_FALLBACK_ROWS>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half,
+                                                           lds, lds + C::BM);
     } else if constexpr (WAY >= 3) {
       // quads through the stage memory for full tiles, the pipelined element-wise way out for the ragged ones
-      static_assert(WAY < 3 || (MT == 3 && NT == 1 && kThreads == 512 && (!SQ || (KS == 1 && S == 1))), "quad way out: 96 couts x 32 pixels per wave, eight waves");
-      static_assert(WAY < 3 || (2 * C::BM + 32 * WM * 32 * WN) <= 2 * C::STAGE, "a round fits the stage memory behind the tables");
+      static_assert(WAY < 3 || WAY == 5 || (MT == 3 && NT == 1 && kThreads == 512 && (!SQ || (KS == 1 && S == 1))), "quad way out: 96 couts x 32 pixels per wave, eight waves");
+      static_assert(WAY < 3 || WAY == 5 || (2 * C::BM + 32 * WM * 32 * WN) <= 2 * C::STAGE, "a round fits the stage memory behind the tables");
       if (c0 + kTileCols <= wo && r0 + kTileRows <= ho && cout0 + C::BM <= cout)
         conv_epilogue_quads<MT, WM, WN, SQ, WAY == 4>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, wo, wm, wn, l31, half,
                                                       lds + 2 * C::BM, lds, lds + C::BM, tid);
@@ -1490,6 +1542,12 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
       rc = launch_conv1x1<1, false, true>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
     else
       rc = launch_conv1x1<1, false, false>(in, packed_w, out, tn, cin, h, w, cout, cp, vin, vout, ep, s);
+  } else if (k == 1 && stride == 1 && d2w && cout > 32 && quad_way_out()) {
+    // (d2w implies no gate / residual / sigmoid / trim: checked above)
+    if (cout > 96)
+      rc = launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, false, 5>(ARGS);
+    else
+      rc = launch_conv<3, 1, 1, 8, 1, 1, PCONV_KC1, false, 5>(ARGS);
   } else if (k == 1 && stride == 1 && !gate && !d2w && act != 4 && cout > 32 && quad_way_out()) {
     if (cout > 96)
       rc = residual ? launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, false, 4>(ARGS) : launch_conv<3, 1, 2, 4, 1, 1, PCONV_KC1, false, 3>(ARGS);
