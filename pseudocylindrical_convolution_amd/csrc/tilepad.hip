@@ -75,74 +75,83 @@ __global__ __launch_bounds__(kBlock) void pseudo_pad_kernel(
 // the interior columns a wider pad of the same buffer could have written before;
 // per halo row the whole row, as pseudo_pad_kernel defines it.  Interior columns
 // past the wrap are the producer's (it trims them to zero).
-// One workgroup per (tile-batch, channel) plane -- blockIdx.x = tc, blockIdx.y splits wide rows: the tile and
-// image indices are computed once per workgroup, a halo row is walked by consecutive lanes (coalesced), and no
-// element needs an integer division.  (r3: the first version decoded a flat 64-bit element index per ring element
-// in a grid-stride loop: four 64-bit divisions per element, 0.6 TB/s, the largest non-convolution, non-entropy
-// item of the codec: 15 ms of a 940 ms step.)
+// Workgroup = (tile, halo row x 256-column strip | the side columns, group of kRingChannels channels).  A thread
+// owns ONE column of a halo row: its source column pair and weight come from the tables once (they depend on the
+// tile and the row only) and stay in registers while it walks the group's channels -- two gathers and one store
+// per element, nothing dependent in front of them, several channels in flight.  (r3's form, one workgroup per
+// (tile, channel) plane, re-read the tables for every channel -- index -> gather -> store, three dependent round
+// trips per element and 25 000 tiny workgroups per launch: 1 TB/s of ring written; r3's first form decoded a flat
+// 64-bit index per element: 0.6 TB/s.)  Same arithmetic per element: identical bits.
+#ifndef PCONV_RING_CHANNELS
+#define PCONV_RING_CHANNELS 8
+#endif
+constexpr int kRingChannels = PCONV_RING_CHANNELS;
+
 __global__ __launch_bounds__(kBlock) void pseudo_pad_ring_kernel(
     float *__restrict__ buf, const int32_t *__restrict__ widths, const int32_t *__restrict__ src_tile,
     const int32_t *__restrict__ src_row, const int32_t *__restrict__ col, const float *__restrict__ wgt,
-    int c, int h, int w, int pad, int store, int npart) {
+    int c, int h, int w, int pad, int store, int npart, int strips) {
   const int sh = h + 2 * store, sw = w + 2 * store;  // storage extent
   const int ow = w + 2 * pad, shift = store - pad;   // view extent / view -> storage offset
   const int per_row = 3 * pad + shift;
-  const unsigned tc = blockIdx.x;                    // tile-batch * c + channel
-  const int pc = (int)(tc % (unsigned)c);
-  const unsigned tb = tc / (unsigned)c;
+  const unsigned tb = blockIdx.x;                    // tile-batch index: image * npart + tile
   const int tg = (int)(tb % (unsigned)npart);
   const unsigned img = tb / (unsigned)npart;
+  const int c0 = blockIdx.z * kRingChannels;
+  const int nc = c - c0 < kRingChannels ? c - c0 : kRingChannels;
   const int valid = widths[tg];
-  float *plane = buf + (size_t)tc * sh * sw;
-  // halo rows: 2 * pad rows of ow elements, columns strided over the workgroups of this plane
-  for (int q = 0; q < 2 * pad; q++) {
+  const size_t cstride = (size_t)sh * sw;            // channel stride of the storage
+  float *plane0 = buf + ((size_t)tb * c + c0) * cstride;
+  const int slot = blockIdx.y;
+  if (slot < 2 * pad * strips) {
+    // a halo row: 2 * pad rows of ow elements
+    const int q = slot / strips, j = (slot % strips) * kBlock + threadIdx.x;
+    if (j >= ow) return;
     const int side = q >= pad, rr = side ? q - pad : q;
     const int rview = side ? pad + h + rr : rr;
     const int e = (tg * 2 + side) * pad + rr;
+    float *dst = plane0 + (size_t)(rview + shift) * sw + shift + j;
+    if (j >= valid + 2 * pad) {
+      for (int k = 0; k < nc; k++) dst[k * cstride] = 0.f;
+      return;
+    }
     const int st = src_tile[e];
     const int svalid = widths[st];
-    const float *src = buf + ((((size_t)(img * npart + st) * c + pc) * sh) + store + src_row[e]) * sw + store;
-    const int32_t *ecol = col + (size_t)e * w;
-    const float *ewgt = wgt + (size_t)e * w;
-    float *dst = plane + (size_t)(rview + shift) * sw + shift;
-    for (int j = blockIdx.y * kBlock + threadIdx.x; j < ow; j += gridDim.y * kBlock) {
-      float v = 0.f;
-      if (j < valid + 2 * pad) {
-        int x = j - pad;
-        x += (x < 0) ? valid : 0;
-        x -= (j >= valid + pad) ? valid : 0;
-        const int qc = ecol[x];
-        const float t = ewgt[x];
-        int q1 = qc + 1;
-        q1 = (q1 >= svalid) ? q1 - svalid : q1;
-        v = src[qc] * t + src[q1] * (1 - t);
-      }
-      dst[j] = v;
-    }
+    int x = j - pad;
+    x += (x < 0) ? valid : 0;
+    x -= (j >= valid + pad) ? valid : 0;
+    const int qc = col[(size_t)e * w + x];
+    const float t = wgt[(size_t)e * w + x];
+    int q1 = qc + 1;
+    q1 = (q1 >= svalid) ? q1 - svalid : q1;
+    const float *src = buf + ((((size_t)(img * npart + st) * c + c0) * sh) + store + src_row[e]) * sw + store;
+#pragma unroll 4
+    for (int k = 0; k < nc; k++) dst[k * cstride] = src[k * cstride + qc] * t + src[k * cstride + q1] * (1 - t);
+    return;
   }
-  // side columns of the interior rows: per row 3 * pad + shift elements (see above), a thread per (row, k)
-  if (blockIdx.y == 0) {
-    for (int i = threadIdx.x; i < h * per_row; i += kBlock) {
-      const int r = i / per_row, k = i - r * per_row;
-      float *line = plane + (size_t)(store + r) * sw;  // storage row of data row r
-      const float *data = line + store;
-      int j;  // view column
-      float v = 0.f;
-      if (k < pad) {
-        j = k;
-        v = data[valid - pad + k];
-      } else if (k < 2 * pad) {
-        j = pad + valid + (k - pad);
-        v = data[k - pad];
-      } else if (k < 3 * pad) {
-        j = pad + w + (k - 2 * pad);
-        if (j < valid + 2 * pad) continue;  // the wrap wrote it
-      } else {
-        j = valid + 2 * pad + (k - 3 * pad);
-        if (j >= pad + w) continue;  // outside the interior: handled as ring
-      }
-      line[j + shift] = v;
+  // side columns of the interior rows: per row 3 * pad + shift elements, a thread per (channel, row, k)
+  const int per_plane = h * per_row;
+  for (int i = threadIdx.x; i < nc * per_plane; i += kBlock) {
+    const int k0 = i / per_plane, i1 = i - k0 * per_plane;
+    const int r = i1 / per_row, k = i1 - r * per_row;
+    float *line = plane0 + k0 * cstride + (size_t)(store + r) * sw;  // storage row of data row r
+    const float *data = line + store;
+    int j;  // view column
+    float v = 0.f;
+    if (k < pad) {
+      j = k;
+      v = data[valid - pad + k];
+    } else if (k < 2 * pad) {
+      j = pad + valid + (k - pad);
+      v = data[k - pad];
+    } else if (k < 3 * pad) {
+      j = pad + w + (k - 2 * pad);
+      if (j < valid + 2 * pad) continue;  // the wrap wrote it
+    } else {
+      j = valid + 2 * pad + (k - 3 * pad);
+      if (j >= pad + w) continue;  // outside the interior: handled as ring
     }
+    line[j + shift] = v;
   }
 }
 
@@ -273,9 +282,11 @@ extern "C" int pconv_pseudo_pad_ring(float *buf, const int32_t *widths, const in
                 "pseudo_pad_ring: bad shape tn=%d c=%d h=%d w=%d pad=%d store=%d", tn, c, h, w, pad, store);
   const long long planes = (long long)tn * c;
   PCONV_REQUIRE(planes <= 0x7fffffffLL, "pseudo_pad_ring: too many planes");
-  const int ysplit = (w + 2 * pad + 1023) / 1024;  // a workgroup walks up to four 256-column strips of a halo row
-  hipLaunchKernelGGL(pseudo_pad_ring_kernel, dim3((unsigned)planes, (unsigned)ysplit), dim3(kBlock), 0, as_stream(stream),
-                     buf, widths, src_tile, src_row, col, wgt, c, h, w, pad, store, npart);
+  const int strips = (w + 2 * pad + kBlock - 1) / kBlock;  // 256-column strips of a halo row
+  const int cgroups = (c + kRingChannels - 1) / kRingChannels;
+  PCONV_REQUIRE(2 * pad * strips + 1 <= 65535 && cgroups <= 65535, "pseudo_pad_ring: grid out of range");
+  hipLaunchKernelGGL(pseudo_pad_ring_kernel, dim3((unsigned)tn, (unsigned)(2 * pad * strips + 1), (unsigned)cgroups), dim3(kBlock),
+                     0, as_stream(stream), buf, widths, src_tile, src_row, col, wgt, c, h, w, pad, store, npart, strips);
   PCONV_LAUNCH_CHECK("pseudo_pad_ring");
   return PCONV_OK;
 }

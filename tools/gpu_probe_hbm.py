@@ -54,6 +54,15 @@ def main():
         view._pconv_ring = (buf, 2)
         ring_elems = 16 * 192 * (2 * p * (2048 + 2 * p) + 64 * 4 * p)
         report("pad %d (ring only, in place) 16x192x64x2048" % p, timed(lambda: pad.forward_ring(view)), 2 * ring_elems * 4)
+    # the codec's batched quarter-scale ring pad (8 frames: 128 tiles of 192 x 32 x 1024, pad 1 in a ring of 1)
+    xq = torch.rand(128, 192, 32, 1024, device=DEV)
+    pad = PCONV.PseudoPadOp(1, 16, ctx.addr(), 0, False)
+    buf = torch.zeros(128, 192, 32 + 2, 1024 + 2, device=DEV)
+    view = buf[:, :, 1:-1, 1:-1]
+    view.copy_(xq)
+    view._pconv_ring = (buf, 1)
+    ring_elems = 128 * 192 * (2 * (1024 + 2) + 32 * 2)
+    report("pad 1 (ring only, in place) 128x192x32x1024", timed(lambda: pad.forward_ring(view)), 2 * ring_elems * 4)
     y = torch.rand(16, 768, 32, 1024, device=DEV)
     dt = PCONV.DtowOp(2, True, 0, False)
     report("dtow x2 16x768x32x1024", timed(lambda: dt.forward(y)), 2 * y.numel() * 4)
