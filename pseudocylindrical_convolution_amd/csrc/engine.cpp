@@ -35,6 +35,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sched.h>
 #include <vector>
 #include "../../include/pconv_coder.h"
 #include "common.h"
@@ -70,16 +71,29 @@ inline void cpu_relax() {
 #endif
 }
 
+// CPUs this process may run on (its affinity mask: bench.py gives every rank a slice of its own)
+static int allowed_cpus() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) != 0) return 1;
+  const int n = CPU_COUNT(&set);
+  return n > 0 ? n : 1;
+}
+
 // Persistent helpers for the per-step arithmetic decoding: job(i) runs for
 // i = 0 (caller) .. n-1 (workers).  A step's decoding takes tens of microseconds,
 // far less than creating and joining threads, so the workers poll a generation
-// counter -- but only for a bounded time (PCONV_ENGINE_SPIN_US, default 60 us:
-// about the host part of a step).  A worker that sees nothing for that long blocks
-// on a condition variable, so the GPU waits of the steps do not keep nimg - 1 cores
-// per group busy (8 ranks x 8 frames would otherwise be ~60 runnable threads).
+// counter.  When the decode's threads (one per frame) have cores of their own they
+// poll through the GPU part of a step as well (~180 us): a worker that had gone to
+// sleep cost a futex wake-up on the critical path of EVERY step (measured: 8 us
+// per step, 0.6 % of the codec).  Otherwise -- more frames than cores, e.g. ranks
+// that share a host's cores -- a worker that sees nothing for 60 us (about the host
+// part of a step) blocks on a condition variable, so that the GPU waits do not keep
+// nimg - 1 cores per group busy.  PCONV_ENGINE_SPIN_US overrides either.
 class StepPool {
  public:
-  explicit StepPool(int n) : n_(n) {
+  StepPool(int n, int call_threads) : n_(n) {
+    spin_us_ = call_threads + 1 <= allowed_cpus() ? 2000 : 60;
     if (const char *env = getenv("PCONV_ENGINE_SPIN_US")) spin_us_ = atoi(env);
     for (int i = 1; i < n_; i++) workers_.emplace_back([this, i] { loop(i); });
   }
@@ -544,6 +558,8 @@ struct pconv_entropy_engine {
   int decode_symbols(Group &g, int s, const Window &cur, double *t_wait, double *t_coder) {
     if (cur.len <= 0) return PCONV_OK;
     const auto t0 = std::chrono::steady_clock::now();
+    // (polling a flag the table kernel publishes behind its rows instead -- the queued chain's protocol -- is
+    // slower here: 183-192 vs 174-180 ms for the 8-frame decode, profiles/round4_decode_spin_poll.txt)
     HIP_TRY(hipStreamSynchronize(g.stream));
     const auto t1 = std::chrono::steady_clock::now();
     PC_TRY(decode_rows(g, s, cur));
@@ -841,7 +857,7 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
       return;
     }
     Group &g = e->groups[k];
-    StepPool pool(g.nimg);
+    StepPool pool(g.nimg, e->nimg);  // (the decode runs one thread per frame of the call)
     g.pool = &pool;
     int rc = PCONV_OK;
     if (chained) {
