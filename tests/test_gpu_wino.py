@@ -69,13 +69,14 @@ def test_wino_is_the_default_and_direct_stays_selectable(hip_backend, monkeypatc
     monkeypatch.setenv("PCONV_CONV3X3", "direct")
     P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 1)
     assert [r[0].split("<")[0] for r in rec.records] == ["wino_conv3x3_kernel", "conv_mfma_kernel"]
-    # what it does not take goes to the direct kernel: stride 2, odd output size, the 12-cout output layer
+    # what it does not take goes to the direct kernels: stride 2, odd output size (conv_mfma_kernel), the 12-cout
+    # output layer (16-cout tiles: conv_small_kernel)
     monkeypatch.setenv("PCONV_CONV3X3", "wino")
     rec.records.clear()
     P().tile_conv2d(owner, x.to(DEV), wt.to(DEV), b.to(DEV), 2)
     P().tile_conv2d(owner, x[:, :, :5].contiguous().to(DEV), wt.to(DEV), b.to(DEV), 1)
     P().tile_conv2d(owner, x.to(DEV), wt[:12].contiguous().to(DEV), b[:12].contiguous().to(DEV), 1)
-    assert all(r[0].startswith("conv_mfma_kernel") for r in rec.records)
+    assert [r[0].split("<")[0] for r in rec.records] == ["conv_mfma_kernel", "conv_mfma_kernel", "conv_small_kernel"]
 
 
 @pytest.mark.parametrize("cfg", [(16, 192, 6, 70, 192), (32, 96, 6, 134, 96), (16, 192, 10, 262, 192)])
