@@ -357,7 +357,8 @@ __device__ __forceinline__ void st4_base_off(float *base, unsigned off, const fl
   *reinterpret_cast<__attribute__((address_space(1))) v4f *>((glb_char_t *)base + off) = q;
 }
 
-// The way out of a FULL tile (no ragged edge, whole cout block) of the 1x1 / GDN layers in quads.  The accumulators
+// The way out of a tile of whole columns and a whole cout block (its last rows may hang over the lower edge) of the
+// 1x1 / GDN layers in quads.  The accumulators
 // hold one pixel per lane (32 consecutive pixels of a cout row per half wave), so the element-wise way out is 48
 // rows x (4-byte load, ~20 address / guard / arithmetic instructions, 4-byte store) per lane: ~1 000 instructions
 // per wave and tile, issued while the CU's other workgroup streams MFMAs -- and a vector instruction gets an issue
@@ -369,15 +370,20 @@ __device__ __forceinline__ void st4_base_off(float *base, unsigned off, const fl
 template <int MT, int WM, int WN, bool SQ, bool RES>
 __device__ __forceinline__ void conv_epilogue_quads(f32x16 (&acc)[MT][1], const ConvEpilogue &ep, const float *in_t,
                                                     float *out_t, const ConvView &vin, const ConvView &vout, int t,
-                                                    int r0, int c0, int cout0, int wo, int wm, int wn, int l31, int half,
-                                                    float *park, const float *bias_s, const float *slope_s, int tid) {
+                                                    int r0, int c0, int cout0, int ho, int wo, int wm, int wn, int l31,
+                                                    int half, float *park, const float *bias_s, const float *slope_s,
+                                                    int tid) {
   constexpr int PX = 32 * WN, QROW = PX / 4, RROWS = 32 * WM, NQR = RROWS * QROW / 512, RSTEP = 512 / QROW;
   static_assert(WM * WN == 8 && RROWS * QROW % 512 == 0 && 32 % RSTEP == 0, "eight waves, whole quads per lane and round");
   const int act = ep.act;
   const int trim_at = ((ep.trim || act == 2 || act == 3) && ep.col_limit) ? ep.col_limit[t % ep.npart] : wo;
   const bool trims = trim_at < c0 + kTileCols;  // (uniform)
   const int row0 = tid / QROW, px = (tid % QROW) * 4;
-  const int orow = r0 + px / kTileCols, ocol = c0 + px % kTileCols;
+  // (a tile may hang over the LOWER edge: a quad lies in one row; rows past the edge read the last row and are not
+  // stored)
+  const int orow_raw = r0 + px / kTileCols, ocol = c0 + px % kTileCols;
+  const bool row_ok = orow_raw < ho;
+  const int orow = row_ok ? orow_raw : ho - 1;
   // quad j of round m: parked row j * RSTEP + row0 = cout block row K(m, j) + row0, K uniform
   auto krow = [](int m, int j) { return ((j * RSTEP) / 32 * MT + m) * 32 + (j * RSTEP) % 32; };
   const unsigned lb_out = (unsigned)(((long long)row0 * vout.cs + (long long)orow * vout.rs + ocol) * 4);
@@ -424,7 +430,7 @@ __device__ __forceinline__ void conv_epilogue_quads(f32x16 (&acc)[MT][1], const 
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = finish(o[k] + bco, xs[k], rs[k], sl, ocol + k >= trim_at, preluc, trimc);
-    st4_base_off(o_t + (size_t)krow(m, j) * vout.cs, lb_out, make_float4(v[0], v[1], v[2], v[3]));
+    if (row_ok) st4_base_off(o_t + (size_t)krow(m, j) * vout.cs, lb_out, make_float4(v[0], v[1], v[2], v[3]));
   };
   auto whole_tile = [&](auto preluc, auto trimc) {
     if constexpr (RES || SQ) static_for_<0, (D < NF ? D : NF)>([&](auto fc) { request(fc); });
@@ -835,9 +841,9 @@ __global__ __launch_bounds__(64 * WM * WN, (KS == 1 && S == 1 && MT == 3) ? PCON
       // quads through the stage memory for full tiles, the pipelined element-wise way out for the ragged ones
       static_assert(WAY < 3 || WAY == 5 || (MT == 3 && NT == 1 && kThreads == 512 && (!SQ || (KS == 1 && S == 1))), "quad way out: 96 couts x 32 pixels per wave, eight waves");
       static_assert(WAY < 3 || WAY == 5 || (2 * C::BM + 32 * WM * 32 * WN) <= 2 * C::STAGE, "a round fits the stage memory behind the tables");
-      if (c0 + kTileCols <= wo && r0 + kTileRows <= ho && cout0 + C::BM <= cout)
-        conv_epilogue_quads<MT, WM, WN, SQ, WAY == 4>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, wo, wm, wn, l31, half,
-                                                      lds + 2 * C::BM, lds, lds + C::BM, tid);
+      if (c0 + kTileCols <= wo && cout0 + C::BM <= cout)
+        conv_epilogue_quads<MT, WM, WN, SQ, WAY == 4>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, ho, wo, wm, wn, l31,
+                                                      half, lds + 2 * C::BM, lds, lds + C::BM, tid);
       else
         conv_epilogue<MT, NT, WN, PCONV_QUAD_FALLBACK_ROWS>(acc, ep, inp, outp, vin, vout, t, r0, c0, cout0, cout, ho, wo, wm, wn, l31, half,
                                                            lds, lds + C::BM);
