@@ -41,12 +41,13 @@ constexpr int kTileCols = 64;
 #ifndef PCONV_KC1
 #define PCONV_KC1 16  // input channels per LDS stage of the 1x1 layers
 #endif
-// quads requested ahead of their turn in conv_epilogue_quads (4 registers each; 8 for the GDN with a residual)
+// quads requested ahead of their turn in conv_epilogue_quads (4 registers each; 8 for the GDN with a residual).
+// Measured 2 / 4 / 6 / 8 ahead (profiles/round4_quad_ahead.txt): level within 2 %, two is never behind.
 #ifndef PCONV_QUAD_AHEAD
-#define PCONV_QUAD_AHEAD 4
+#define PCONV_QUAD_AHEAD 2
 #endif
 #ifndef PCONV_QUAD_AHEAD_GDN
-#define PCONV_QUAD_AHEAD_GDN 3
+#define PCONV_QUAD_AHEAD_GDN 2
 #endif
 
 template <int ROWS, int KS, int S>
