@@ -78,10 +78,13 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
 // known, the causal masks make each output equal to the step-by-step one)
 int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
                  const float *slope, const float *residual, float *y, int cin, int cout, int constrain,
-                 int pad_out, void *stream);
-// CDF rows and labels of all symbols, written in stream order
+                 int pad_out, int first_idx, int n_idx, int s_lo, int s_hi, void *stream);
+// (first_idx, n_idx, s_lo, s_hi: only the (position, group) pairs of the wavefront steps [s_lo, s_hi), found among
+// the schedule entries first_idx .. first_idx + n_idx - 1; the whole schedule: 0, npos, 0, INT_MAX)
+// CDF rows and labels of the symbols of those steps, written in stream order
 int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
-                   int nstep, float bias, float total, float beta, void *stream);
+                   int nstep, float bias, float total, float beta, int first_idx, int n_idx, int s_lo, int s_hi,
+                   void *stream);
 
 // halos and wrap columns of a whole buffer of `nrep` images with C channels from
 // its interior (bulk mode, after a layer has been evaluated everywhere)

@@ -45,6 +45,7 @@ namespace {
 
 constexpr int kLayers = 12;
 constexpr int kPad = 2;
+constexpr int kMaxEncodeRanges = 8;  // step ranges of a group's encode (Group::enc_done)
 
 #define HIP_TRY(expr)                                                     \
   do {                                                                    \
@@ -171,6 +172,8 @@ struct Group {
   EeGeom geom;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
+  std::vector<int> enc_bounds;         // encoder: step ranges (see encode_tables)
+  hipEvent_t enc_done[8] = {nullptr};  // ... and "this range's rows are on the host"
   float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
   float *act[kLayers] = {nullptr};  // (3*nimg*npart, h+2p, w+2p, 3G), persistent across steps
   int32_t *tables_d = nullptr, *labels_d = nullptr;
@@ -240,6 +243,7 @@ struct pconv_entropy_engine {
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_TRY(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest));
     HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    for (int k = 0; k < kMaxEncodeRanges; k++) HIP_TRY(hipEventCreateWithFlags(&g.enc_done[k], hipEventDisableTiming));
     g.step_row.assign(nsteps + 1, 0);
     for (int s = 0; s < nsteps; s++) g.step_row[s + 1] = g.step_row[s] + window(s).len * n;
     HIP_TRY(hipMalloc(&g.step_row_d, g.step_row.size() * 4));
@@ -420,6 +424,8 @@ struct pconv_entropy_engine {
       if (g.flags_h) (void)hipHostFree(g.flags_h);
       freed(g.counter_d);
       if (g.done) (void)hipEventDestroy(g.done);
+      for (hipEvent_t &ev : g.enc_done)
+        if (ev) (void)hipEventDestroy(ev);
       if (g.stream) (void)hipStreamDestroy(g.stream);
     }
     if (entry) (void)hipEventDestroy(entry);
@@ -470,14 +476,28 @@ struct pconv_entropy_engine {
     return PCONV_OK;
   }
 
-  // every layer once over all (plane, group) pairs: the encoder knows all symbols
-  int network_bulk(Group &g) {
+  // schedule entries that have a (position, group) pair in the wavefront steps [s_lo, s_hi): planes
+  // s_lo - ngroup + 1 .. s_hi - 1 (the schedule is sorted by plane)
+  void step_range_entries(int s_lo, int s_hi, int *first, int *count) const {
+    const int nplane = rows + w - 1;
+    const int p_lo = std::max(0, s_lo - (ngroup - 1)), p_hi = std::min(nplane, s_hi);
+    *first = sched_start[p_lo];
+    *count = p_hi > p_lo ? sched_start[p_hi] - sched_start[p_lo] : 0;
+  }
+
+  // every layer once over the (plane, group) pairs of the steps [s_lo, s_hi): the encoder knows all symbols.  A
+  // pair's unmasked inputs lie in steps <= its own (masks of constrain 5 / 6), i.e. in this range's previous
+  // layer or in an earlier range: ranges are evaluated in step order, layer by layer inside a range; what a
+  // window holds of later steps is stale but finite and meets a masked (zero) weight.
+  int network_bulk(Group &g, int s_lo, int s_hi) {
     const int hid = 3 * ngroup;
+    int first = 0, count = 0;
+    step_range_entries(s_lo, s_hi, &first, &count);
     for (int l = 0; l < kLayers; l++) {
       const float *in = (l == 0) ? g.ctx : g.act[l - 1];
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
       PC_TRY(ee_conv_bulk(&g.geom, in, l == 0, lw[l], lb[l], la[l], res, g.act[l], layer_cin(l), hid,
-                          l == 0 ? 5 : 6, l == kLayers - 1 ? 0 : kPad, g.stream));
+                          l == 0 ? 5 : 6, l == kLayers - 1 ? 0 : kPad, first, count, s_lo, s_hi, g.stream));
       if (l != kLayers - 1) PC_TRY(ee_halo_bulk(&g.geom, g.act[l], hid, 3 * g.nimg, g.stream));
     }
     return PCONV_OK;
@@ -504,13 +524,46 @@ struct pconv_entropy_engine {
                          g.stream));
       }
     } else {
-      PC_TRY(network_bulk(g));
-      PC_TRY(ee_tables_bulk(&g.geom, g.act[kLayers - 1], sym, g.tables_d, g.labels_d, nlevels, bias, total, beta,
-                            g.stream));
+      // Step ranges (g.enc_bounds: 0 = b_0 < b_1 < ... = nsteps): a range's rows go to the host as soon as they
+      // exist and an event says so, so that the arithmetic coder works on range k while the GPU is on range k + 1.
+      // One range for the groups whose coding hides behind the next group's GPU work anyway; the call's LAST
+      // group in several: its coding was the encoder's tail (15 ms of GPU idle per 8-frame step).
+      const int nrange = (int)g.enc_bounds.size() - 1;
+      for (int k = 0; k < nrange; k++) {
+        const int s_lo = g.enc_bounds[k], s_hi = g.enc_bounds[k + 1];
+        int first = 0, count = 0;
+        step_range_entries(s_lo, s_hi, &first, &count);
+        PC_TRY(network_bulk(g, s_lo, s_hi));
+        PC_TRY(ee_tables_bulk(&g.geom, g.act[kLayers - 1], sym, g.tables_d, g.labels_d, nlevels, bias, total, beta, first,
+                              count, s_lo, s_hi, g.stream));
+        const size_t r0 = g.step_row[s_lo], r1 = g.step_row[s_hi];
+        if (r1 > r0) {
+          HIP_TRY(hipMemcpyAsync(g.tables_h + r0 * cols, g.tables_d + r0 * cols, (r1 - r0) * cols * 4, hipMemcpyDeviceToHost,
+                                 g.stream));
+          HIP_TRY(hipMemcpyAsync(g.labels_h + r0, g.labels_d + r0, (r1 - r0) * 4, hipMemcpyDeviceToHost, g.stream));
+        }
+        HIP_TRY(hipEventRecord(g.enc_done[k], g.stream));
+      }
+      return PCONV_OK;
     }
     HIP_TRY(hipMemcpyAsync(g.tables_h, g.tables_d, row * cols * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(g.labels_h, g.labels_d, row * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipEventRecord(g.enc_done[0], g.stream));
     return PCONV_OK;
+  }
+
+  // step ranges of a group's encode: `nrange` ranges of about equal numbers of symbols
+  void set_encode_ranges(Group &g, int nrange) const {
+    nrange = std::max(1, std::min(nrange, kMaxEncodeRanges));
+    g.enc_bounds.assign(1, 0);
+    const long long total_rows = g.step_row[nsteps];
+    for (int k = 1; k < nrange; k++) {
+      const long long want = total_rows * k / nrange;
+      int s = g.enc_bounds.back() + 1;
+      while (s < nsteps && g.step_row[s] < want) s++;
+      if (s < nsteps && s > g.enc_bounds.back()) g.enc_bounds.push_back(s);
+    }
+    g.enc_bounds.push_back(nsteps);
   }
 
   // decoder, GPU phase of step s for one group (everything is queued, nothing waits).
@@ -662,14 +715,16 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
   // the analysis transform of the following frames the tables arrived 0.4-0.5 s late).  The
   // first group's tables are on the host half-way and its frames are coded on the CPU while
   // the GPU works on the second group and on what the caller queues after this call.
+  // PCONV_ENGINE_ENCODE_RANGES: step ranges of the call's last group (default 4; 1 = as one piece)
+  static const int last_ranges = getenv("PCONV_ENGINE_ENCODE_RANGES") ? atoi(getenv("PCONV_ENGINE_ENCODE_RANGES")) : 4;
   for (size_t k = 0; k < e->groups.size(); k++) {
     Group &g = e->groups[k];
+    e->set_encode_ranges(g, (k + 1 == e->groups.size() && !e->stepwise_encoder) ? last_ranges : 1);
     hipStream_t own = g.stream;
     g.stream = caller;
     const int rc = e->encode_tables(g, symbols);
     g.stream = own;
     PC_TRY(rc);
-    HIP_TRY(hipEventRecord(g.done, caller));
   }
   e->enc_status.store(0);
   e->enc_errors.assign(e->nimg, std::string());
@@ -694,7 +749,9 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
         return;
       }
       const auto t0 = std::chrono::steady_clock::now();
-      if (hipEventSynchronize(g.done) != hipSuccess) {  // the group's tables and labels are on the host
+      // the rows of the group's first step range are on the host (the frames' threads wait for the later ranges
+      // themselves, each in front of the range's first step)
+      if (hipEventSynchronize(g.enc_done[0]) != hipSuccess) {
         e->enc_status.store(PCONV_ELAUNCH);
         e->enc_errors[g.first] = "ee_encode: the encode stream failed";
         return;
@@ -704,8 +761,22 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
       for_each_image(g.nimg, [&](int i) {
         const int img = g.first + i;
         pconv_coder *c = e->coders[img];
+        if (hipSetDevice(device) != hipSuccess) {
+          e->enc_status.store(PCONV_ELAUNCH);
+          e->enc_errors[img] = "ee_encode: hipSetDevice failed in a coder thread";
+          return;
+        }
         int rc = pconv_coder_start_encoder(c);
+        size_t range = 0;
         for (int s = 0; s < e->nsteps && rc >= 0; s++) {
+          if (range + 1 < g.enc_bounds.size() - 1 && s == g.enc_bounds[range + 1]) {
+            range++;
+            if (hipEventSynchronize(g.enc_done[range]) != hipSuccess) {
+              e->enc_status.store(PCONV_ELAUNCH);
+              e->enc_errors[img] = "ee_encode: the encode stream failed";
+              return;
+            }
+          }
           const size_t len = (size_t)(g.step_row[s + 1] - g.step_row[s]) / g.nimg;
           if (!len) continue;
           const size_t r0 = (size_t)g.step_row[s] + (size_t)i * len;

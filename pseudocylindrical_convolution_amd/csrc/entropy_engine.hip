@@ -496,13 +496,18 @@ template <int CIN, int ITER, int BLOCK, int PP>
 __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ slope, const float *__restrict__ residual,
-    float *__restrict__ y, int cout, int constrain, int pad_out) {
+    float *__restrict__ y, int cout, int constrain, int pad_out, int first_idx, int n_idx, int s_lo, int s_hi) {
+  // Step range [s_lo, s_hi) (the whole schedule: 0, INT_MAX): only the (position, group) pairs whose wavefront
+  // step plane + group lies in it are evaluated and stored; first_idx / n_idx = the schedule entries that have
+  // such a pair (planes s_lo - ngroup + 1 .. s_hi - 1).  The encoder's last group is coded in step ranges so
+  // that the arithmetic coder starts on the first range while the GPU is on the second (engine.cpp).
   constexpr int RED = CIN * KK;
   constexpr int kPosPerWg = BLOCK / kWave * PP;
   __shared__ __attribute__((aligned(16))) float wl2[2][slab_floats(CIN)];  // double-buffered weight slab
-  const int nchunk = (g.npos + kPosPerWg - 1) / kPosPerWg;
+  const int nchunk = (n_idx + kPosPerWg - 1) / kPosPerWg;
   const int chunk = blockIdx.x % nchunk;
   const int pn = blockIdx.x / nchunk;  // replica-major image index, 0 .. 3*nimg
+  const int end_idx = first_idx + n_idx;
   const int set = pn / g.nimg;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -511,7 +516,14 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   const int tile_elems = (h + 2 * PAD) * win * CIN;
   const int xi = shared_input ? pn % g.nimg : pn;
   const float *ximg = x + (size_t)xi * g.npart * tile_elems;
-  const int idx0 = (chunk * (BLOCK / kWave) + wave) * PP;
+  const int idx0 = first_idx + (chunk * (BLOCK / kWave) + wave) * PP;
+  // groups any position of this workgroup has in the range (the schedule is sorted by plane): uniform loop bounds
+  const int wg_first = first_idx + chunk * kPosPerWg;
+  const int wg_last = wg_first + kPosPerWg - 1 < end_idx - 1 ? wg_first + kPosPerWg - 1 : end_idx - 1;
+  const int plane_min = g.pos_plane[wg_first], plane_max = g.pos_plane[wg_last];
+  const int tc_lo = s_lo - plane_max > 0 ? s_lo - plane_max : 0;
+  const int tc_hi = s_hi - plane_min < g.ngroup ? s_hi - plane_min : g.ngroup;
+  if (tc_lo >= tc_hi) return;  // (uniform for the workgroup)
   unsigned off[ITER];  // byte offsets of this lane's taps inside a window
   {
     TapWalk<CIN> tw(lane);
@@ -523,9 +535,11 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
   }
   float xv[PP][ITER];
   size_t obase[PP];
+  int pplane[PP];
 #pragma unroll
   for (int j = 0; j < PP; j++) {
-    const int idx = idx0 + j < g.npos ? idx0 + j : 0;
+    const int idx = idx0 + j < end_idx ? idx0 + j : first_idx;
+    pplane[j] = __builtin_amdgcn_readfirstlane(g.pos_plane[idx]);
     const Pos p = decode_pos(__builtin_amdgcn_readfirstlane(g.order[idx]), h, w);
     const float *xin = ximg + (size_t)p.tg * tile_elems + ((size_t)p.th * win + p.tw) * CIN;
 #pragma unroll
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     obase[j] = ((((size_t)pn * g.npart + p.tg) * (h + 2 * pad_out) + p.th + pad_out) * (w + 2 * pad_out) +
                 p.tw + pad_out) * cout;
   }
-  stage_weights<CIN, BLOCK>(wl2[0], wp + (size_t)set * g.ngroup * slab_floats(CIN), threadIdx.x);
+  stage_weights<CIN, BLOCK>(wl2[tc_lo & 1], wp + ((size_t)set * g.ngroup + tc_lo) * slab_floats(CIN), threadIdx.x);
   // bias and slope of the set's outputs in LDS, once: loaded per group in front of their use they sat behind the
   // store of the group before (vmcnt counts stores too, and a guarded load is waited for with vmcnt(0)): one
   // exposed store -> load round trip per group and wave
@@ -549,10 +563,10 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
     bs_tab[1][i] = slope ? slope[set * cout + i] : 1.f;  // (v * 1 is v)
   }
   __syncthreads();
-  for (int tc = 0; tc < g.ngroup; tc++) {
+  for (int tc = tc_lo; tc < tc_hi; tc++) {
     // the next group's slab goes to the other buffer while this one is used (its
     // last readers passed the barrier that ended the previous iteration)
-    if (tc + 1 < g.ngroup)
+    if (tc + 1 < tc_hi)
       stage_weights<CIN, BLOCK>(wl2[(tc + 1) & 1], wp + ((size_t)set * g.ngroup + tc + 1) * slab_floats(CIN),
                                 threadIdx.x);
     const float *wl = wl2[tc & 1];
@@ -609,7 +623,8 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
       const float tot = butterfly12(acc, lane);
       const int j = lane >> 4, quad = (lane >> 2) & 3;
       const int o = quad == 0 ? 0 : (quad == 2 ? 1 : 2);
-      if ((lane & 3) == 0 && quad != 3 && idx0 + j < g.npos) {
+      const int pl = j == 0 ? pplane[0] : (j == 1 ? pplane[1] : (j == 2 ? pplane[2] : pplane[3]));
+      if ((lane & 3) == 0 && quad != 3 && idx0 + j < end_idx && pl + tc >= s_lo && pl + tc < s_hi) {
         const int pout = tc * GO + o;
         const size_t ob = j == 0 ? obase[0] : (j == 1 ? obase[1] : (j == 2 ? obase[2] : obase[3]));
         float v = tot + bs_tab[0][pout];
@@ -626,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void ee_conv_bulk_kernel(
       for (int j = 0; j < PP; j++) {
 #pragma unroll
         for (int o = 0; o < GO; o++) acc[j][o] = butterfly_sum(acc[j][o]);
-        if (idx0 + j < g.npos && lane < GO) {
+        if (idx0 + j < end_idx && lane < GO && pplane[j] + tc >= s_lo && pplane[j] + tc < s_hi) {
           float v = acc[j][0];
 #pragma unroll
           for (int o = 1; o < GO; o++) v = (lane == o) ? acc[j][o] : v;
@@ -850,14 +865,16 @@ __global__ void ee_tables8_kernel(EeGeom g, const float *__restrict__ y, int32_t
 // all symbols at once, rows in stream order [step][img][position in the step's window]
 __global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, const float *__restrict__ symbols,
                                       int32_t *__restrict__ table, int32_t *__restrict__ labels, int nstep,
-                                      float bias, float total, float beta, long long count) {
+                                      float bias, float total, float beta, long long count, int first_idx, int n_idx,
+                                      int s_lo, int s_hi) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (long long)gridDim.x * blockDim.x) {
-    const int idx = (int)(i % g.npos);
-    const int tc = (int)((i / g.npos) % g.ngroup);
-    const int n = (int)(i / g.npos / g.ngroup);
+    const int idx = first_idx + (int)(i % n_idx);
+    const int tc = (int)((i / n_idx) % g.ngroup);
+    const int n = (int)(i / n_idx / g.ngroup);
     const int plane = g.pos_plane[idx];
     const int s = plane + tc;
+    if (s < s_lo || s >= s_hi) continue;  // (another step range's row)
     const int rows = g.h * g.npart;
     const int st = s - g.ngroup + 1 < 0 ? 0 : s - g.ngroup + 1;
     const int end = s < rows + g.w - 2 ? s + 1 : rows + g.w - 1;
@@ -882,10 +899,13 @@ __global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, con
 }  // namespace
 
 int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
-                   int nstep, float bias, float total, float beta, void *stream) {
-  const long long count = (long long)g->nimg * g->ngroup * g->npos;
+                   int nstep, float bias, float total, float beta, int first_idx, int n_idx, int s_lo, int s_hi,
+                   void *stream) {
+  PCONV_REQUIRE(first_idx >= 0 && n_idx >= 0 && first_idx + n_idx <= g->npos && s_lo < s_hi, "ee_tables_bulk: bad range");
+  if (n_idx == 0) return PCONV_OK;
+  const long long count = (long long)g->nimg * g->ngroup * n_idx;
   hipLaunchKernelGGL(ee_tables_bulk_kernel, dim3(pconv_grid(count)), dim3(256), 0, as_stream(stream), *g, y_last,
-                     symbols, table, labels, nstep, bias, total, beta, count);
+                     symbols, table, labels, nstep, bias, total, beta, count, first_idx, n_idx, s_lo, s_hi);
   PCONV_LAUNCH_CHECK("ee_tables_bulk");
   return PCONV_OK;
 }
@@ -970,21 +990,23 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
 
 int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float *packed_w, const float *bias,
                  const float *slope, const float *residual, float *y, int cin, int cout, int constrain, int pad_out,
-                 void *stream) {
+                 int first_idx, int n_idx, int s_lo, int s_hi, void *stream) {
   PCONV_REQUIRE(cout == 3 * g->ngroup, "ee_conv_bulk: cout must be 3 per group");
+  PCONV_REQUIRE(first_idx >= 0 && n_idx >= 0 && first_idx + n_idx <= g->npos && s_lo < s_hi, "ee_conv_bulk: bad range");
+  if (n_idx == 0) return PCONV_OK;
   constexpr int kBlock = 1024;
   // positions per wave (each staged weight slab then serves 16x as many): as many as
   // fit 128 registers beside the window (ITER values per position)
   const int iter = (cin * KK + kWave - 1) / kWave;
   const int pp = iter <= 20 ? 4 : 1;
   const long long per_wg = kBlock / kWave * pp;
-  const long long nchunk = (g->npos + per_wg - 1) / per_wg;
+  const long long nchunk = (n_idx + per_wg - 1) / per_wg;
   const long long grid = (long long)3 * g->nimg * nchunk;
   PCONV_REQUIRE(grid > 0 && grid < (1LL << 31), "ee_conv_bulk: grid %lld out of range", grid);
 #define EE_BULK(CIN, ITER)                                                                                   \
   hipLaunchKernelGGL((ee_conv_bulk_kernel<CIN, ITER, kBlock, (ITER <= 20 ? 4 : 1)>), dim3((unsigned)grid), dim3(kBlock), 0,        \
                      as_stream(stream), *g, x, shared_input, packed_w, bias, slope, residual, y, cout, constrain, \
-                     pad_out)
+                     pad_out, first_idx, n_idx, s_lo, s_hi)
   if (cin == 14) {
     EE_BULK(14, 6);
   } else if (cin == 42) {
