@@ -11,15 +11,16 @@ GPU) and exits with their code.  One step = every rank encodes and decodes its
 own shard of frames (--frames-per-gpu, independent frames, no data-path
 collective: weak scaling).  Rank 0 prints ONE JSON line.  Besides the contract
 fields it carries
-  roofline      the dominant kernel (the Winograd F(2x2,3x3) tile convolution on the
-                fp32 matrix cores, csrc/wino.hip) timed with events on its launch
+  roofline      the dominant kernel (the Winograd F(4x2,3x3) tile convolution on the
+                fp32 matrix cores, csrc/wino42.hip) timed with events on its launch
                 stream during the timed steps.  `achieved` / `frac` count the
-                multiply-adds the algorithm EXECUTES on the matrix cores (16 per
-                2x2 outputs, input and output channel), so frac <= 1 is a fraction
+                multiply-adds the algorithm EXECUTES on the matrix cores (24 per
+                4x2 outputs, input and output channel), so frac <= 1 is a fraction
                 of the fp32 MFMA peak; `direct_equivalent` is the same time priced
-                in direct-convolution flops (x 2.25, SURVEY 8d's per-pixel figure).
+                in direct-convolution flops (x 3, SURVEY 8d's per-pixel figure).
                 `traffic` / `mfma_busy` from the rocprofv3 --pmc summary under
                 profiles/ when that summary is of the same kernel
+  hbm           the gather / permute kernels of the same steps against the HBM roof
   cpu_baseline  the CPU oracle port of the same codec on a bounded sample
 
 --mode analysis times the analysis transform alone (BASELINE config #3:
@@ -85,12 +86,14 @@ def rank_cpus(local_rank, local_world, allowed=None):
 def cpu_quota():
     """CPUs the cgroup lets this job use (a GPU box shows all host CPUs in the affinity mask of a
     container that owns a share of them); None when there is no quota"""
+    override = os.environ.get("PCONV_CGROUP_CPU_MAX")   # another cpu.max-format file (tests; csrc/engine.cpp reads it too)
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(override or "/sys/fs/cgroup/cpu.max") as f:
             quota, period = f.read().split()[:2]
         return None if quota == "max" else max(1, int(int(quota) / int(period)))
     except (OSError, ValueError):
-        pass
+        if override:
+            return None
     try:
         with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
             quota = int(f.read())
@@ -101,17 +104,22 @@ def cpu_quota():
         return None
 
 
-def pin_rank(local_rank, local_world):
+def pin_rank(local_rank, local_world, emulate=False):
     """Before this rank creates any thread or touches the GPU: keep it (and every thread it starts:
     torch's intra-op pool, the engine's queueing / polling / coder threads) on its own slice of the
-    host cores, so that 8 ranks x (2 drivers + up to 8 coder threads + OpenMP) do not migrate over
-    each other's cores.  PCONV_BENCH_PIN=0 turns it off.  Returns the number of cores kept."""
+    host cores, so that 8 ranks x (4 drivers + up to 8 coder threads + OpenMP) do not migrate over
+    each other's cores.  PCONV_BENCH_PIN=0 turns it off.  Returns the number of cores kept.
+    emulate (--emulate-local-world): this is the ONLY rank, but it gets what rank 0 of `local_world`
+    ranks would get at best -- its affinity slice cut down to quota / local_world CPUs, so that the
+    threads really compete for a rank's share of the host."""
     if not hasattr(os, "sched_setaffinity") or os.environ.get("PCONV_BENCH_PIN", "1") == "0":
         return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cpus = rank_cpus(local_rank, local_world)
-    os.sched_setaffinity(0, cpus)
     quota = cpu_quota()
     n = max(1, len(cpus) if quota is None else min(len(cpus), max(1, quota // max(local_world, 1))))
+    if emulate:
+        cpus = cpus[:n]
+    os.sched_setaffinity(0, cpus)
     n = min(n, 32)   # the host side of a rank is a handful of driver / coder threads; torch's pool never needs more
     os.environ["OMP_NUM_THREADS"] = str(n)
     torch.set_num_threads(n)
@@ -397,6 +405,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", default="2048x4096",
                     help="HxW of the CPU baseline sample (default: the metric frame, ~80 s on a 16-core share; 1024x2048: ~20 s)")
     ap.add_argument("--no-check", action="store_true", help="skip the round-trip / stationarity assertions")
+    ap.add_argument("--emulate-local-world", type=int, default=0, metavar="N",
+                    help="ONE real rank on one GPU with the host share rank 0 of N ranks on this node would get at "
+                         "best: pinned to cgroup quota / N CPUs, LOCAL_WORLD_SIZE=N for the engine's thread / spin "
+                         "rules (csrc/engine.cpp).  The 1 -> N curve of the HOST side without an N-GPU node")
     args = ap.parse_args(argv)
     if args.height is None:
         args.height = 2048 if args.mode == "codec" else 1024
@@ -414,7 +426,13 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = device_type == "cuda"
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    cores = pin_rank(local, local_world)   # before any thread of this rank exists
+    emulate = int(getattr(args, "emulate_local_world", 0) or 0)
+    if emulate:
+        if world != 1:
+            raise SystemExit("--emulate-local-world is a one-rank experiment (WORLD_SIZE=%d)" % world)
+        local_world = emulate
+        os.environ["LOCAL_WORLD_SIZE"] = str(emulate)   # the native engine sizes its host threads by it
+    cores = pin_rank(local, local_world, emulate=bool(emulate))   # before any thread of this rank exists
     strong = args.frames_total is not None
     if strong:
         if args.frames_total < world:
@@ -450,10 +468,12 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         PCONV.conv_probe, PCONV.hbm_probe = probe, hbm
     fence()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()   # user + system time of every thread of this rank
     for _ in range(args.steps):
         load.step()
     fence()
     elapsed = time.perf_counter() - t0
+    host_busy = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # host cores this rank kept busy, on average
     if on_gpu:
         PCONV.conv_probe = PCONV.hbm_probe = None
     extra = {} if args.no_check else load.check()
@@ -505,9 +525,14 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         frames_total = max(totals["frames"], 1.0)
         config = {"workload": load.describe(), "frames_per_gpu": load.F,
                   "parallelism": "frames sharded, no data-path collective",
-                  "tile_conv_s_per_step": round(conv_s, 4), "cores_per_rank": cores}
+                  "residency": "frames and reconstructions resident in HBM; PCIe carries CDF rows / symbols / streams only "
+                               "(copying 8 frames in and out would add ~32 ms per step, DESIGN.md section 6)",
+                  "tile_conv_s_per_step": round(conv_s, 4), "cores_per_rank": cores,
+                  "host_cores_busy": round(host_busy, 2)}
         if strong:
             config["frames_total"] = args.frames_total
+        if emulate:
+            config["emulated_local_world"] = emulate
         if load.name == "codec":
             config["bpp"] = round(totals["bits"] / (frames_total * load.H * load.W), 4)
             if not args.no_check:

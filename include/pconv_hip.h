@@ -421,6 +421,15 @@ int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, 
                        const float *slope, void *stream);
 long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e);
 int pconv_ee_steps(const pconv_entropy_engine *e);
+/* Host side of the engine (no reference counterpart: the reference drives its loop from one Python
+ * thread, pseudo_codec.py:145-160; its only multi-process code is one process per GPU,
+ * test/trainDDP_Full.py:83-86,201-204).  pconv_ee_host_cpus: CPUs this rank's host threads can count
+ * on = min(affinity mask, cgroup CPU quota / LOCAL_WORLD_SIZE).  pconv_ee_spin_us: microseconds an
+ * idle decode worker polls before it blocks when a call runs `call_threads` host threads (one per
+ * frame): 2000 (through the GPU part of a step) only if call_threads + 1 <= pconv_ee_host_cpus(),
+ * else 60; PCONV_ENGINE_SPIN_US overrides.  Neither touches the GPU. */
+int pconv_ee_host_cpus(void);
+int pconv_ee_spin_us(int call_threads);
 /* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */
 int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream);
 /* the same in two halves: begin queues the GPU part IN `stream` and starts the host thread that

@@ -80,6 +80,8 @@ _HIP_SIGNATURES = {
     # native entropy engine
     "pconv_ee_set_layer": [P, I, P, P, P, P],
     "pconv_ee_steps": [P],
+    "pconv_ee_host_cpus": [],
+    "pconv_ee_spin_us": [I],
     "pconv_ee_encode": [P, P, P],
     "pconv_ee_encode_begin": [P, P, P],
     "pconv_ee_encode_end": [P, P],

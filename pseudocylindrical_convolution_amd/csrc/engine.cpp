@@ -72,8 +72,8 @@ inline void cpu_relax() {
 #endif
 }
 
-// CPUs this process may run on (its affinity mask: bench.py gives every rank a slice of its own)
-static int allowed_cpus() {
+// CPUs in the affinity mask (bench.py gives every rank a slice of its own)
+static int affinity_cpus() {
   cpu_set_t set;
   CPU_ZERO(&set);
   if (sched_getaffinity(0, sizeof(set), &set) != 0) return 1;
@@ -81,21 +81,77 @@ static int allowed_cpus() {
   return n > 0 ? n : 1;
 }
 
+// CPU quota of the cgroup in whole CPUs (0: no quota).  A GPU box shows all 256 host CPUs in the
+// affinity mask of a container that owns 16 of them: the mask alone says nothing about how many
+// threads can really run.  cgroup v2 `cpu.max` ("quota period" | "max period"), then v1
+// cfs_quota_us / cfs_period_us; PCONV_CGROUP_CPU_MAX names another cpu.max-format file (tests).
+static int cgroup_cpu_quota() {
+  const char *override_path = getenv("PCONV_CGROUP_CPU_MAX");
+  if (FILE *f = fopen(override_path ? override_path : "/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[64] = {0};
+    long long period = 0;
+    const int n = fscanf(f, "%63s %lld", quota, &period);
+    fclose(f);
+    if (n == 2 && period > 0 && strcmp(quota, "max") != 0) {
+      const long long q = atoll(quota);
+      if (q > 0) return (int)std::max(1LL, q / period);
+    }
+    return 0;
+  }
+  if (override_path) return 0;
+  long long q = -1, period = 0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    if (fscanf(f, "%lld", &q) != 1) q = -1;
+    fclose(f);
+  }
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+    if (fscanf(f, "%lld", &period) != 1) period = 0;
+    fclose(f);
+  }
+  return (q > 0 && period > 0) ? (int)std::max(1LL, q / period) : 0;
+}
+
+// CPUs the host threads of THIS rank can count on: the affinity mask, cut down to the rank's share
+// of the cgroup quota -- quota / LOCAL_WORLD_SIZE, the ranks of a node share one container
+// (test/trainDDP_Full.py:83-86,201-204: one process per GPU on one host).
+static int allowed_cpus() {
+  int n = affinity_cpus();
+  const int quota = cgroup_cpu_quota();
+  if (quota > 0) {
+    int ranks = 1;
+    if (const char *env = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(env));
+    n = std::min(n, std::max(1, quota / ranks));
+  }
+  return n;
+}
+
+// How long an idle StepPool worker polls before it blocks, for a call that runs `call_threads`
+// host threads side by side (one per frame: group drivers + their workers).  Through the whole GPU
+// part of a step (2 ms covers it) only when every one of them AND the caller's own thread have a
+// CPU of this rank's share; otherwise about the host part of a step, so that the GPU waits do not
+// keep frames - groups cores busy that other ranks (or other threads of this one) need.
+static int step_pool_spin_us(int call_threads) {
+  int spin = call_threads + 1 <= allowed_cpus() ? 2000 : 60;
+  if (const char *env = getenv("PCONV_ENGINE_SPIN_US")) spin = atoi(env);
+  return spin;
+}
+
 // Persistent helpers for the per-step arithmetic decoding: job(i) runs for
 // i = 0 (caller) .. n-1 (workers).  A step's decoding takes tens of microseconds,
 // far less than creating and joining threads, so the workers poll a generation
-// counter.  When the decode's threads (one per frame) have cores of their own they
-// poll through the GPU part of a step as well (~180 us): a worker that had gone to
-// sleep cost a futex wake-up on the critical path of EVERY step (measured: 8 us
-// per step, 0.6 % of the codec).  Otherwise -- more frames than cores, e.g. ranks
-// that share a host's cores -- a worker that sees nothing for 60 us (about the host
-// part of a step) blocks on a condition variable, so that the GPU waits do not keep
-// nimg - 1 cores per group busy.  PCONV_ENGINE_SPIN_US overrides either.
+// counter.  When the decode's threads (one per frame) have cores of their own IN THIS
+// RANK'S SHARE of the host (affinity mask and cgroup quota / ranks on the node:
+// allowed_cpus) they poll through the GPU part of a step as well (~180 us): a worker
+// that had gone to sleep cost a futex wake-up on the critical path of EVERY step
+// (measured: 8 us per step, 0.6 % of the codec).  Otherwise -- more frames than
+// cores, e.g. ranks that share a host's cores -- a worker that sees nothing for 60 us
+// (about the host part of a step) blocks on a condition variable, so that the GPU
+// waits do not keep nimg - 1 cores per group busy.  PCONV_ENGINE_SPIN_US overrides
+// either (step_pool_spin_us).
 class StepPool {
  public:
   StepPool(int n, int call_threads) : n_(n) {
-    spin_us_ = call_threads + 1 <= allowed_cpus() ? 2000 : 60;
-    if (const char *env = getenv("PCONV_ENGINE_SPIN_US")) spin_us_ = atoi(env);
+    spin_us_ = step_pool_spin_us(call_threads);
     for (int i = 1; i < n_; i++) workers_.emplace_back([this, i] { loop(i); });
   }
   ~StepPool() {
@@ -692,6 +748,10 @@ int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, 
   e->bound[layer] = true;
   return PCONV_OK;
 }
+
+// host-side sizing of the engine, exported so that it can be checked without a GPU (tests/test_host_share.py)
+int pconv_ee_host_cpus(void) { return allowed_cpus(); }
+int pconv_ee_spin_us(int call_threads) { return step_pool_spin_us(call_threads); }
 
 long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e) { return e ? (long long)e->sym_per_img : -1; }
 int pconv_ee_steps(const pconv_entropy_engine *e) { return e ? e->nsteps : -1; }

@@ -38,8 +38,14 @@ class OracleToyWorkload(object):
                      for i in range(self.F)]
         self.dir = os.environ["PCONV_DRYRUN_DIR"]
         import json
-        with open(os.path.join(self.dir, "affinity_r%d.json" % rank), "w") as f:   # what bench.pin_rank left this rank
-            json.dump({"cpus": sorted(os.sched_getaffinity(0)), "frames": self.F, "torch_threads": torch.get_num_threads()}, f)
+        # what bench.pin_rank left this rank, and how the native engine would size its host side here (the two
+        # entry points touch no GPU: csrc/engine.cpp allowed_cpus / step_pool_spin_us)
+        from pseudocylindrical_convolution_amd import _native
+        lib = _native.hip_lib()
+        with open(os.path.join(self.dir, "affinity_r%d.json" % rank), "w") as f:
+            json.dump({"cpus": sorted(os.sched_getaffinity(0)), "frames": self.F, "torch_threads": torch.get_num_threads(),
+                       "engine_host_cpus": lib.pconv_ee_host_cpus(), "engine_spin_us_8_frames": lib.pconv_ee_spin_us(8),
+                       "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}, f)
         self.bits, self.bits_first, self.back = 0, None, None
 
     def step(self):

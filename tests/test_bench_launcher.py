@@ -13,11 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "helpers", "bench_dryrun_rank.py")
 
 
-def _run(nproc, tmp_path, frames=("--frames-per-gpu", "2")):
+def _run(nproc, tmp_path, frames=("--frames-per-gpu", "2"), env=None):
+    child_env = {"PCONV_DRYRUN_DIR": str(tmp_path)}
+    child_env.update(env or {})
     code = ("import sys; sys.path.insert(0, %r); import bench; "
             "sys.exit(bench.launch_ranks(%d, ['--gpus', '%d', '--steps', '2', '--warmup', '1', '--prime', '0', "
-            "%r, %r], script=%r, env={'PCONV_DRYRUN_DIR': %r}))"
-            % (ROOT, nproc, nproc, frames[0], frames[1], WORKER, str(tmp_path)))
+            "%r, %r], script=%r, env=%r))"
+            % (ROOT, nproc, nproc, frames[0], frames[1], WORKER, child_env))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -42,6 +44,32 @@ def test_launcher_starts_two_ranks_and_reduces(tmp_path):
         assert not set(kept[0]["cpus"]) & set(kept[1]["cpus"])
         assert sorted(kept[0]["cpus"] + kept[1]["cpus"]) == allowed
         assert two["config"]["cores_per_rank"] == len(kept[0]["cpus"]) == kept[0]["torch_threads"]
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_on_one_host_share_the_quota(tmp_path):
+    """BASELINE config #5's process model (one process per GPU on one host, test/trainDDP_Full.py:83-86,201-204)
+    at its full width on the CPU: 8 gloo ranks of bench.run.  Every rank keeps a slice of its own of the host
+    CPUs, the native engine of every rank sizes its host threads by quota / 8 (not by the affinity mask), and the
+    ranks that would poll through the GPU part of a step never add up to more runnable spinners than the quota."""
+    allowed = sorted(os.sched_getaffinity(0))
+    quota = 16                                                  # the GPU box's container: 16 CPUs, shared by the ranks
+    (tmp_path / "cpu.max").write_text("%d 100000" % (quota * 100000))
+    out = _run(8, tmp_path, ("--frames-per-gpu", "1"), env={"PCONV_CGROUP_CPU_MAX": str(tmp_path / "cpu.max")})
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak"
+    pixels = 8 * 256 * 1024
+    assert abs(out["value"] * 1e6 * out["ms_per_step"] * 1e-3 - pixels) / pixels < 0.01
+    kept = [json.load(open(os.path.join(str(tmp_path), "affinity_r%d.json" % r))) for r in range(8)]
+    assert all(k["local_world"] == 8 for k in kept)
+    if len(allowed) >= 8:
+        seen = [c for k in kept for c in k["cpus"]]
+        assert len(seen) == len(set(seen)) and sorted(seen) == allowed      # disjoint, covering
+    for k in kept:
+        assert k["engine_host_cpus"] == min(len(k["cpus"]), quota // 8)
+        # 8 frames per rank = 8 decode threads + the caller on 2 CPUs: the workers block instead of polling
+        assert k["engine_spin_us_8_frames"] == 60
+    spinners = sum(8 for k in kept if k["engine_spin_us_8_frames"] > 60)
+    assert spinners <= quota
 
 
 @pytest.mark.timeout(1200)
