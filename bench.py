@@ -120,10 +120,43 @@ def pin_rank(local_rank, local_world, emulate=False):
     if emulate:
         cpus = cpus[:n]
     os.sched_setaffinity(0, cpus)
+    # ... and the threads that exist already (numpy's BLAS pool is started by `import torch`): a rank's share of
+    # the host holds for ALL its threads
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
+    except OSError:
+        pass
     n = min(n, 32)   # the host side of a rank is a handful of driver / coder threads; torch's pool never needs more
     os.environ["OMP_NUM_THREADS"] = str(n)
     torch.set_num_threads(n)
     return n
+
+
+def thread_table():
+    """[(name, allowed CPUs, user + system seconds)] of every thread of this process (diagnostic of
+    --emulate-local-world: which threads burn the rank's share of the host, and whether any escaped the pin)"""
+    rows, tick = [], os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            base = "/proc/self/task/%s/" % tid
+            with open(base + "stat") as f:
+                st = f.read()
+            name = st[st.index("(") + 1:st.rindex(")")]
+            fields = st[st.rindex(")") + 2:].split()
+            cpu = (int(fields[11]) + int(fields[12])) / tick
+            allowed = ""
+            with open(base + "status") as f:
+                for line in f:
+                    if line.startswith("Cpus_allowed_list"):
+                        allowed = line.split(":")[1].strip()
+            rows.append((name, allowed, cpu))
+    except (OSError, ValueError, IndexError):
+        pass
+    return rows
 
 
 def launch_ranks(nproc, argv, script=None, env=None):
@@ -474,6 +507,14 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     fence()
     elapsed = time.perf_counter() - t0
     host_busy = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # host cores this rank kept busy, on average
+    if os.environ.get("PCONV_BENCH_THREADS") and rank == 0:
+        per = {}
+        for name, allowed, cpu in thread_table():
+            d = per.setdefault((name, allowed), [0, 0.0])
+            d[0] += 1
+            d[1] += cpu
+        for (name, allowed), (n, cpu) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            sys.stderr.write("[bench threads] %-18s x%-3d cpus %-12s %.2f s\n" % (name, n, allowed, cpu))
     if on_gpu:
         PCONV.conv_probe = PCONV.hbm_probe = None
     extra = {} if args.no_check else load.check()

@@ -154,6 +154,10 @@ int pconv_quant(const float *x, const float *weight, float *level_tab, float *ou
                 float *out_idx, float *count, const int32_t *widths, int tn, int c, int h,
                 int w, int levels, int npart, void *stream);
 
+/* ClipData.forward (model_zoo_v2.py:8-26), in place on n floats: x * 0.01 below 0, 1 + (x - 1) * 0.01 above 1,
+ * x otherwise -- the same three roundings as the reference's masked assignments, in one pass. */
+int pconv_leaky_clip(float *x, long long n, void *stream);
+
 /* PseudoDQuantOp.forward  (pseudo_dquant_cuda.cu:24-70)
  * weight (wc, levels) raw parameter, level_tab (wc, levels) scratch */
 int pconv_dquant(const float *x, const float *weight, float *level_tab, float *out,
@@ -430,6 +434,13 @@ int pconv_ee_steps(const pconv_entropy_engine *e);
  * else 60; PCONV_ENGINE_SPIN_US overrides.  Neither touches the GPU. */
 int pconv_ee_host_cpus(void);
 int pconv_ee_spin_us(int call_threads);
+/* How an engine of `nimg` frames lays out its host side here (any pointer may be NULL): lock-step groups (= decoder
+ * chains = driver threads), threads that arithmetic-decode a group's frames (0 = one per frame), queued-ahead (1)
+ * or host-driven (0) chain, waits that sleep instead of spinning.  With nimg + 1 <= pconv_ee_host_cpus(): the
+ * measured best of profiles/round3_decode_groups.txt; otherwise (a rank with a small share of the host) at most
+ * one group per CPU, one decoding thread per group, host-driven chain, sleeping waits
+ * (profiles/round5_host_share.txt).  PCONV_ENGINE_GROUPS / _WORKERS / _CHAIN / _BLOCKING_SYNC override. */
+int pconv_ee_host_plan(int nimg, int *groups, int *group_threads, int *queued_chain, int *blocking_sync);
 /* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */
 int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream);
 /* the same in two halves: begin queues the GPU part IN `stream` and starts the host thread that

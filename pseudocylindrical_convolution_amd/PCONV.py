@@ -509,6 +509,23 @@ class SphereUsliceOp(_SphereResample):
                  self.npart_, p, _stream(x.device))
         return [out]
 
+    def forward_into(self, x, out):
+        """forward() with the caller's output tensor (n, c, h * npart, w), contiguous -- a frame of a batch the
+        caller assembles: no op-owned buffer, no copy afterwards (engine.CodecEngine.reconstruct)"""
+        _require_gpu(x, "SphereUsliceOp")
+        p = self.pad_
+        tn, c, hp, wp = x.shape
+        h, w = hp - 2 * p, wp - 2 * p
+        n = tn // self.npart_
+        if tn % self.npart_ or tuple(out.shape) != (n, c, h * self.npart_, w) or not out.is_contiguous() \
+                or out.dtype != torch.float32 or out.device != x.device:
+            raise PconvError("SphereUsliceOp.forward_into: output %s does not fit input %s" % (tuple(out.shape), tuple(x.shape)))
+        wd, col, coef = self._tables("pconv_host_uslice_taps", h * self.npart_, w, x)
+        with _HbmTimed("uslice_kernel", "SphereUslice w%d" % out.shape[3], 8.0 * out.numel(), x.device):
+            call("pconv_sphere_uslice", _ptr(x), _ptr(out), _ptr(wd), _ptr(col), _ptr(coef), n, c, h, w,
+                 self.npart_, p, _stream(x.device))
+        return out
+
     def backward(self, grad):
         """grad of the ERP image -> grad of the (padded) tile stack, zero outside the valid
         interior (sphere_uslice_cuda.cu:128-200)"""
@@ -1207,6 +1224,16 @@ def _ring_output(shape, ring, like):
     out = buf[:, :, ring:-ring, ring:-ring]
     out._pconv_ring = (buf, ring)
     return out
+
+
+def leaky_clip_(x):
+    """ClipData.forward (model_zoo_v2.py:8-26) in place on a contiguous fp32 GPU tensor, one pass"""
+    _require_gpu(x, "leaky_clip_")
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise PconvError("leaky_clip_: contiguous float32 tensor expected")
+    with _HbmTimed("leaky_clip_kernel", "ClipData n%d" % x.numel(), 8.0 * x.numel(), x.device):
+        call("pconv_leaky_clip", _ptr(x), x.numel(), _stream(x.device))
+    return x
 
 
 def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=None, ring=0):

@@ -37,6 +37,7 @@ _HIP_SIGNATURES = {
     "pconv_dtow": [P, P, I, I, I, I, I, I, P],
     "pconv_quant": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_dquant": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "pconv_leaky_clip": [P, LL, P],
     "pconv_project": [P, P, P, I, I, I, I, I, I, I, I, P],
     "pconv_context_reshape": [P, P, I, I, I, I, I, P],
     "pconv_mask_constrain": [P, I, I, I, I, I, P],
@@ -82,6 +83,7 @@ _HIP_SIGNATURES = {
     "pconv_ee_steps": [P],
     "pconv_ee_host_cpus": [],
     "pconv_ee_spin_us": [I],
+    "pconv_ee_host_plan": [I, P, P, P, P],
     "pconv_ee_encode": [P, P, P],
     "pconv_ee_encode_begin": [P, P, P],
     "pconv_ee_encode_end": [P, P],

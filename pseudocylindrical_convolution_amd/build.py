@@ -26,6 +26,7 @@ HIP_SOURCES = [
     "pointwise.hip",
     "entropy.hip",
     "entropy_engine.hip",
+    "entropy_mfma.hip",
     "conv.hip",
     "wino.hip",
     "wino42.hip",

@@ -400,7 +400,9 @@ int pconv_coder_encodes(pconv_coder *c, const int32_t *table, int ncode, const i
     // the codec's rows (8 symbols, total 65536): narrow<true>() with the interval in registers and the two
     // divisions by the total as shifts; rows of another shape end the fast loop
     uint64_t low = c->low, high = c->high, pending = c->pending;
-    c->sink.reserve((size_t)n * 5 + 64);  // (<= 33 bits leave the state per symbol, deferred bits included)
+    // <= 33 bits leave the state per symbol, deferred bits of THIS call included; the bits deferred by earlier
+    // calls (`pending` at entry) are flushed through the checked put_run() but land in the same buffer
+    c->sink.reserve((size_t)n * 5 + 64 + (size_t)(pending / 8) + 8);
     int rc = 0;
     for (; i < n; i++) {
       const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * 9);

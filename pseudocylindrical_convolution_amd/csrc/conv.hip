@@ -1514,6 +1514,11 @@ extern "C" int pconv_conv2d(const float *in, const float *packed_w, const float 
                 "conv2d: strides overlap");
   PCONV_REQUIRE(((long long)(16 - 1) * vin.cs + (long long)(h - 1) * vin.rs + w) * 4 < (1LL << 32),
                 "conv2d: input channel stride too large for 32-bit byte offsets inside a chunk");
+  // the quad ways out (conv_epilogue_quads) address output and residual as a 64-bit uniform base + a 32-bit byte
+  // offset per lane that spans up to 32 cout rows of a parked round: their strides are independent of the input's
+  PCONV_REQUIRE(((long long)(32 - 1) * vout.cs + (long long)(oh - 1) * vout.rs + ow) * 4 < (1LL << 32) &&
+                    (!residual || ((long long)(32 - 1) * ep.vres.cs + (long long)(ho - 1) * ep.vres.rs + wo) * 4 < (1LL << 32)),
+                "conv2d: output / residual channel stride too large for 32-bit byte offsets inside a round");
   int rc;
 #define ARGS in, packed_w, out, tn, cin, h, w, cout, cp, ho, wo, vin, vout, ep, s
   // workgroup tiles (measured on MI355X, 192->192 3x3 at 16 x 64 x 2048: 127 TFLOP/s):

@@ -125,6 +125,44 @@ static int allowed_cpus() {
   return n;
 }
 
+// A call that runs `call_threads` host threads side by side (one per frame) on fewer CPUs than that (+ the
+// caller's own thread): the rank's share of the host is the scarce resource, not the GPU.  Measured on one
+// MI355X with the rank pinned to 2 / 4 CPUs (profiles/round5_host_share.txt, 8 frames): four polling
+// drivers + four polling workers 58-75 MPix/s; the frames of a group decoded one after the other by the
+// group's driver (no workers) 74-85; at 2 CPUs two groups instead of four 80; waits that sleep instead of
+// spinning: the same speed at half the CPU time (8 ranks x 2 spinning cores would exhaust a 16-CPU quota).
+static bool host_constrained(int call_threads) { return call_threads + 1 > allowed_cpus(); }
+
+// The host side of a call of `nimg` frames, decided in ONE place (pconv_ee_host_plan exports it for the tests):
+struct HostPlan {
+  int groups;         // lock-step groups = decoder chains = driver threads
+  int group_threads;  // threads that arithmetic-decode a group's frames (the driver included); 0 = one per frame
+  int queued_chain;   // 1: the queued-ahead chain, 0: the host-driven one
+  int blocking_sync;  // 1: the runtime's waits sleep instead of spinning
+};
+static HostPlan host_plan(int nimg) {
+  HostPlan p;
+  const bool constrained = host_constrained(nimg);
+  // two groups up to five frames, four from six on (r3, profiles/round3_decode_groups.txt); eight make the chains
+  // wait for each other (4 hardware queues).  A group is a host thread: never more of them than this rank has
+  // CPUs when the frames do not fit anyway
+  p.groups = nimg >= 6 ? 4 : (nimg >= 2 ? 2 : 1);
+  if (constrained) p.groups = std::min(p.groups, std::max(1, allowed_cpus()));
+  if (const char *env = getenv("PCONV_ENGINE_GROUPS")) p.groups = atoi(env);
+  p.groups = std::max(1, std::min(p.groups, nimg));
+  p.group_threads = constrained ? 1 : 0;
+  if (const char *env = getenv("PCONV_ENGINE_WORKERS")) p.group_threads = std::max(1, atoi(env));
+  const int largest = (nimg + p.groups - 1) / p.groups;
+  // queued / host-driven, measured (MI355X, 4096x2048, two groups): 94 / 103 ms for one frame, 110 / 113 for two,
+  // 141 / 137 for four, 212 / 197 for eight; the queued chain keeps two host threads per group busy (one queues,
+  // one polls): with fewer CPUs than frames it loses badly (8 frames on 2 CPUs: 1 956 ms against 220)
+  p.queued_chain = largest < 4 && nimg < 6 && !constrained;
+  if (const char *env = getenv("PCONV_ENGINE_CHAIN")) p.queued_chain = env[0] != 'h';
+  p.blocking_sync = constrained;
+  if (const char *env = getenv("PCONV_ENGINE_BLOCKING_SYNC")) p.blocking_sync = atoi(env) != 0;
+  return p;
+}
+
 // How long an idle StepPool worker polls before it blocks, for a call that runs `call_threads`
 // host threads side by side (one per frame: group drivers + their workers).  Through the whole GPU
 // part of a step (2 ms covers it) only when every one of them AND the caller's own thread have a
@@ -150,8 +188,12 @@ static int step_pool_spin_us(int call_threads) {
 // either (step_pool_spin_us).
 class StepPool {
  public:
-  StepPool(int n, int call_threads) : n_(n) {
+  // njobs jobs per run() on `threads` threads (the caller included): thread k takes jobs k, k + threads, ...
+  StepPool(int njobs, int threads, int call_threads) : njobs_(njobs), n_(std::max(1, std::min(threads, njobs))) {
     spin_us_ = step_pool_spin_us(call_threads);
+    // more runnable threads than CPUs: a polling thread gives its time slice away instead of keeping the
+    // thread it waits for off the core
+    polite_ = call_threads + 1 > allowed_cpus();
     for (int i = 1; i < n_; i++) workers_.emplace_back([this, i] { loop(i); });
   }
   ~StepPool() {
@@ -161,17 +203,23 @@ class StepPool {
   }
   void run(const std::function<void(int)> &job) {
     if (n_ == 1) {
-      job(0);
+      for (int j = 0; j < njobs_; j++) job(j);
       return;
     }
     job_ = &job;
     done_.store(0, std::memory_order_relaxed);
     publish();
-    job(0);
-    while (done_.load(std::memory_order_acquire) < n_ - 1) cpu_relax();
+    for (int j = 0; j < njobs_; j += n_) job(j);
+    while (done_.load(std::memory_order_acquire) < n_ - 1) relax();
   }
 
  private:
+  void relax() {
+    if (polite_)
+      sched_yield();
+    else
+      cpu_relax();
+  }
   void publish() {
     gen_.fetch_add(1, std::memory_order_release);
     if (sleepers_.load(std::memory_order_acquire) > 0) {
@@ -185,8 +233,8 @@ class StepPool {
       const auto t0 = std::chrono::steady_clock::now();
       int spins = 0;
       while (gen_.load(std::memory_order_acquire) == seen) {
-        cpu_relax();
-        if ((++spins & 255) == 0 &&
+        relax();
+        if ((spin_us_ <= 0 || (++spins & (polite_ ? 7 : 255)) == 0) &&
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us_) {
           std::unique_lock<std::mutex> lk(mu_);
           sleepers_.fetch_add(1, std::memory_order_acq_rel);
@@ -196,12 +244,13 @@ class StepPool {
       }
       seen = gen_.load(std::memory_order_acquire);
       if (stop_.load(std::memory_order_acquire)) return;
-      (*job_)(i);
+      for (int j = i; j < njobs_; j += n_) (*job_)(j);
       done_.fetch_add(1, std::memory_order_release);
     }
   }
-  int n_;
+  int njobs_, n_;
   int spin_us_ = 60;
+  bool polite_ = false;
   std::vector<std::thread> workers_;
   const std::function<void(int)> *job_ = nullptr;
   std::atomic<int> gen_{0}, done_{0}, sleepers_{0};
@@ -259,6 +308,11 @@ struct pconv_entropy_engine {
   int32_t *pos_plane_d = nullptr;
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
+  // matrix-core form of the encoder's hidden layers (entropy_mfma.hip): weights as MFMA fragments, the list of
+  // position blocks; mfma_waves == 0: not available for this shape (the vector kernel takes every layer)
+  float *lwf[kLayers] = {nullptr};
+  void *mfma_blocks_d = nullptr;
+  int mfma_nblocks = 0, mfma_rp = 0, mfma_ct = 0, mfma_waves = 0;
   const float *lb[kLayers] = {nullptr}, *la[kLayers] = {nullptr};
   bool bound[kLayers] = {false};
   std::vector<Group> groups;
@@ -444,14 +498,32 @@ struct pconv_entropy_engine {
       stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
     }
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
+    {
+      // PCONV_EE_BULK=valu keeps the vector kernel for every layer of the encoder (A/B; identical streams)
+      const char *env = getenv("PCONV_EE_BULK");
+      int rp = 0, ct = 0, wv = 0;
+      if (!(env && env[0] == 'v') && ngroup == 14 && ee_mfma_block_shape(h, 3 * ngroup, &rp, &ct, &wv)) {
+        std::vector<int32_t> blk;
+        for (int t = 0; t < npart; t++)
+          for (int r0 = 0; r0 < h; r0 += 2 * rp)
+            for (int c0 = 0; c0 < widths[t]; c0 += 16 * ct) {
+              const int32_t rec[4] = {t, r0, c0, 0};
+              blk.insert(blk.end(), rec, rec + 4);
+            }
+        if (!blk.empty()) {
+          HIP_TRY(hipMalloc(&mfma_blocks_d, blk.size() * 4));
+          HIP_TRY(hipMemcpy(mfma_blocks_d, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
+          for (int l = 1; l < kLayers; l++) HIP_TRY(hipMalloc(&lwf[l], (size_t)ee_mfma_packed_floats(3, 3 * ngroup) * 4));
+          mfma_nblocks = (int)(blk.size() / 4);
+          mfma_rp = rp, mfma_ct = ct, mfma_waves = wv;
+        }
+      }
+    }
     // decoder chains run side by side, one per group: two groups up to five frames, four from six on
     // (r3, whole codec at 8 frames, host-driven chains: 2 / 3 / 4 groups 194-199 / 183-187 / 178-180 ms per
     // decode; at 4 frames two groups of two on the queued chain stay best: profiles/round3_decode_groups.txt);
     // eight make the chains wait for each other (4 hardware queues)
-    int ngroups = nimg >= 6 ? 4 : (nimg >= 2 ? 2 : 1);
-    if (const char *env = getenv("PCONV_ENGINE_GROUPS")) ngroups = atoi(env);
-    if (ngroups > nimg) ngroups = nimg;
-    if (ngroups < 1) ngroups = 1;
+    const int ngroups = host_plan(nimg).groups;
     groups.resize(ngroups);
     for (int k = 0, first = 0; k < ngroups; k++) {
       const int n = nimg / ngroups + (k < nimg % ngroups ? 1 : 0);
@@ -471,6 +543,8 @@ struct pconv_entropy_engine {
     freed(widths_d); freed(order_d); freed(sched_start_d); freed(vh_col); freed(vh_wgt);
     freed(pos_plane_d); freed(pos_d); freed(halo_d); freed(tap_in_d); freed(tap_hid_d);
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
+    for (int l = 0; l < kLayers; l++) freed(lwf[l]);
+    freed(mfma_blocks_d);
     for (Group &g : groups) {
       freed(g.ctx); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
       for (int l = 0; l < kLayers; l++) freed(g.act[l]);
@@ -486,6 +560,13 @@ struct pconv_entropy_engine {
     }
     if (entry) (void)hipEventDestroy(entry);
     for (pconv_coder *c : coders) pconv_coder_free(c);
+  }
+
+  // "Stale but finite" no longer holds after a failed call (a launch that did not run, an aborted chain) or
+  // with new weights (an overflow of the old ones would stay in the buffers: 0 * inf = nan): the next call
+  // zeroes again.
+  void distrust_buffers() {
+    for (Group &g : groups) g.zeroed = false;
   }
 
   // group streams start after everything the caller has queued (weights, symbols)
@@ -510,7 +591,9 @@ struct pconv_entropy_engine {
   // (the causal mask: a stale value of the previous call is finite, so fmaf(stale, 0, acc) == acc).
   int clear(Group &g) {
     HIP_TRY(hipMemsetAsync(g.counter_d, 0, 64, g.stream));  // table-kernel block counter, scatter relay word
-    if (g.zeroed) return PCONV_OK;
+    // PCONV_ENGINE_CLEAR_EVERY_CALL=1: the pre-r4 behaviour (every call starts from zeroed buffers)
+    static const bool every_call = getenv("PCONV_ENGINE_CLEAR_EVERY_CALL") && atoi(getenv("PCONV_ENGINE_CLEAR_EVERY_CALL"));
+    if (g.zeroed && !every_call) return PCONV_OK;
     HIP_TRY(hipMemsetAsync(g.ctx, 0, ctx_elems(g.nimg) * 4, g.stream));
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMemsetAsync(g.act[l], 0, act_elems(l, g.nimg) * 4, g.stream));
     g.zeroed = true;
@@ -552,8 +635,13 @@ struct pconv_entropy_engine {
     for (int l = 0; l < kLayers; l++) {
       const float *in = (l == 0) ? g.ctx : g.act[l - 1];
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
-      PC_TRY(ee_conv_bulk(&g.geom, in, l == 0, lw[l], lb[l], la[l], res, g.act[l], layer_cin(l), hid,
-                          l == 0 ? 5 : 6, l == kLayers - 1 ? 0 : kPad, first, count, s_lo, s_hi, g.stream));
+      if (mfma_waves && lwf[l])
+        PC_TRY(ee_conv_bulk_mfma(&g.geom, mfma_blocks_d, mfma_nblocks, mfma_rp, mfma_ct, mfma_waves, in, 0, lwf[l], lb[l],
+                                 la[l], res, g.act[l], layer_cin(l), hid, l == kLayers - 1 ? 0 : kPad, s_lo, s_hi,
+                                 g.stream));
+      else
+        PC_TRY(ee_conv_bulk(&g.geom, in, l == 0, lw[l], lb[l], la[l], res, g.act[l], layer_cin(l), hid,
+                            l == 0 ? 5 : 6, l == kLayers - 1 ? 0 : kPad, first, count, s_lo, s_hi, g.stream));
       if (l != kLayers - 1) PC_TRY(ee_halo_bulk(&g.geom, g.act[l], hid, 3 * g.nimg, g.stream));
     }
     return PCONV_OK;
@@ -717,6 +805,10 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
     pconv_set_error("ee_create: bad argument");
     return nullptr;
   }
+  // Host-constrained rank: the runtime's waits (stream / event synchronisation of the drivers and the coder
+  // threads) sleep on an interrupt instead of spinning.  A device-wide flag of this process -- one process per
+  // GPU is the deployment model (test/trainDDP_Full.py:83-86); PCONV_ENGINE_BLOCKING_SYNC=0 / 1 forces it.
+  if (host_plan(nimg).blocking_sync) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   pconv_entropy_engine *e = new pconv_entropy_engine();
   e->npart = npart; e->ngroup = ngroup; e->h = h; e->w = w; e->nimg = nimg;
   e->bias = bias; e->nlevels = nlevels; e->total = total; e->beta = beta;
@@ -743,15 +835,27 @@ int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, 
   PCONV_REQUIRE(e && layer >= 0 && layer < kLayers && weight && bias, "ee_set_layer: bad argument");
   PC_TRY(ee_pack_weight(weight, e->lw[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, layer == 0 ? 5 : 6,
                         stream));
+  if (e->lwf[layer])
+    PC_TRY(ee_pack_weight_mfma(weight, e->lwf[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, 6, stream));
   e->lb[layer] = bias;
   e->la[layer] = slope;
   e->bound[layer] = true;
+  e->distrust_buffers();
   return PCONV_OK;
 }
 
 // host-side sizing of the engine, exported so that it can be checked without a GPU (tests/test_host_share.py)
 int pconv_ee_host_cpus(void) { return allowed_cpus(); }
 int pconv_ee_spin_us(int call_threads) { return step_pool_spin_us(call_threads); }
+int pconv_ee_host_plan(int nimg, int *groups, int *group_threads, int *queued_chain, int *blocking_sync) {
+  PCONV_REQUIRE(nimg > 0, "ee_host_plan: bad argument");
+  const HostPlan p = host_plan(nimg);
+  if (groups) *groups = p.groups;
+  if (group_threads) *group_threads = p.group_threads;
+  if (queued_chain) *queued_chain = p.queued_chain;
+  if (blocking_sync) *blocking_sync = p.blocking_sync;
+  return PCONV_OK;
+}
 
 long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e) { return e ? (long long)e->sym_per_img : -1; }
 int pconv_ee_steps(const pconv_entropy_engine *e) { return e ? e->nsteps : -1; }
@@ -776,7 +880,7 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
   // first group's tables are on the host half-way and its frames are coded on the CPU while
   // the GPU works on the second group and on what the caller queues after this call.
   // PCONV_ENGINE_ENCODE_RANGES: step ranges of the call's last group (default 4; 1 = as one piece)
-  static const int last_ranges = getenv("PCONV_ENGINE_ENCODE_RANGES") ? atoi(getenv("PCONV_ENGINE_ENCODE_RANGES")) : 4;
+  const int last_ranges = getenv("PCONV_ENGINE_ENCODE_RANGES") ? atoi(getenv("PCONV_ENGINE_ENCODE_RANGES")) : 4;
   for (size_t k = 0; k < e->groups.size(); k++) {
     Group &g = e->groups[k];
     e->set_encode_ranges(g, (k + 1 == e->groups.size() && !e->stepwise_encoder) ? last_ranges : 1);
@@ -784,6 +888,7 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
     g.stream = caller;
     const int rc = e->encode_tables(g, symbols);
     g.stream = own;
+    if (rc < 0) e->distrust_buffers();
     PC_TRY(rc);
   }
   e->enc_status.store(0);
@@ -883,6 +988,7 @@ int pconv_ee_encode_end(pconv_entropy_engine *e, void *stream) {
             e->enc_wait * 1e3, e->enc_coder * 1e3);
   (void)stream;  // everything was queued in the caller's stream: nothing to join
   if (e->enc_status.load() < 0) {
+    e->distrust_buffers();
     for (const std::string &m : e->enc_errors)
       if (!m.empty()) {
         pconv_set_error("%s", m.c_str());
@@ -937,11 +1043,9 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
   //     host-driven: 94 / 103 ms for one frame, 110 / 113 for two, 141 / 137 for four, 212 / 197 for eight
   //     (four frames per group: 276 KB of rows per step); r3: from six frames on four groups, host-driven
   //     (8 frames: 178-180 ms; four groups on the queued chain 206-209).  PCONV_ENGINE_CHAIN=queued|host overrides.
-  const char *chain_env = getenv("PCONV_ENGINE_CHAIN");
+  const HostPlan plan = host_plan(e->nimg);
   const int ng = (int)e->groups.size();
-  int largest = 0;
-  for (const Group &g : e->groups) largest = std::max(largest, g.nimg);
-  const bool chained = chain_env ? chain_env[0] != 'h' : (largest < 4 && e->nimg < 6);
+  const bool chained = plan.queued_chain != 0;
   std::vector<int> rcs(ng, PCONV_OK);
   std::vector<std::string> errors(ng);
   std::vector<double> waits(ng, 0.0), coders(ng, 0.0);
@@ -988,7 +1092,10 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
       return;
     }
     Group &g = e->groups[k];
-    StepPool pool(g.nimg, e->nimg);  // (the decode runs one thread per frame of the call)
+    // one thread per frame of the call, unless the frames do not have CPUs of their own (host_plan: then the
+    // driver decodes its frames one after the other) or PCONV_ENGINE_WORKERS says otherwise
+    const int cap = plan.group_threads > 0 ? plan.group_threads : g.nimg;
+    StepPool pool(g.nimg, cap, e->nimg);
     g.pool = &pool;
     int rc = PCONV_OK;
     if (chained) {
@@ -1050,6 +1157,7 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
     if (rcs[k] < 0) {
       pconv_set_error("%s", errors[k].c_str());
       for (Group &g : e->groups) (void)hipStreamSynchronize(g.stream);
+      e->distrust_buffers();
       return rcs[k];
     }
   PC_TRY(e->join(caller));

@@ -1,0 +1,346 @@
+// Encoder ("bulk") form of a hidden layer of the entropy network on the fp32 matrix cores.
+//
+// Same numbers as ee_conv_bulk_kernel / ee_step_kernel (entropy_engine.hip), bit for bit: the
+// published order of the masked 5 x 5 convolution (entropy.hip; the reference:
+// entropy_conv_cuda_v2.cu:326-380, driven by pseudo_codec.py:97-114) is
+//   lane l of 64 sums the reduction entries kk = l, l + 64, l + 128, ... as ONE fmaf chain
+//   from 0, then the 64 partial sums meet in an xor butterfly 32, 16, 8, 4, 2, 1.
+// A v_mfma_f32_16x16x4_f32 IS a k-ascending fmaf chain (tools/mfma16_chain_probe.hip: 0 of
+// 256 outputs differ), so the chain of "lane class" l is a GEMM of its own,
+//   C_l[out][pos] = sum_j W[out][l + 64 j] * X[pos][l + 64 j],  j = 0 .. ITER - 1 ascending,
+// 17 deep for 42 input channels (5 instructions, K padded to 20 with zero weights: a chain
+// that never holds -0 is unchanged by + (+-0)), and the butterfly is the fixed tree
+//   s1[l] = C_l + C_(l^32), s2[l] = s1[l] + s1[l^16], ... , total = s5[0] + s5[1]
+// (float addition commutes, so every lane of the butterfly holds this one value).  The classes
+// are visited in bit-reversed order, which makes the tree a stack of at most six partial sums:
+// class order index i = 8 a + b  ->  l = 8 bitrev3(b) + bitrev3(a); after class i as many
+// levels fold as i has trailing ones.  Masked taps are zeros in the packed weights, as in
+// the slabs of the other kernels: on the matrix cores they cost nothing extra.
+//
+// Work split.  A workgroup takes a block of BR rows x BC columns of one tile of one replica
+// (set x image) and stages its (BR + 4) x (BC + 4) x CIN patch of the channels-last padded
+// input in LDS ONCE (the vector kernel gathers every window from L2: 10.85 M L2 requests per
+// launch, "waits on its window gathers", profiles/round4_bench_pmc.json).  A wave owns two
+// stacked rows x 16 columns = two position tiles (matrix columns) and all 48 (42) outputs =
+// three output tiles (matrix rows): 6 accumulator tiles per class, 30 MFMAs per class.  The
+// weights come pre-packed as MFMA A-fragments in class order (ee_pack_weight_mfma: 4 KB per
+// class and set), streamed through a 4-slot LDS ring two classes ahead (register-staged), one
+// barrier per class (~1000 matrix cycles per wave).
+//
+// The causal masks make a (position, group) output independent of everything the decoder
+// would not have yet, so -- like ee_conv_bulk_kernel -- the kernel may evaluate ALL groups of
+// a position at once; a step range [s_lo, s_hi) only filters the stores (and skips blocks
+// that hold no pair of the range).
+#include <stdlib.h>
+#include <atomic>
+#include "common.h"
+#include "ee_kernels.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int K5 = 5, KK = 25, HALF = 2, PAD = 2, GO = 3;
+constexpr int kMT = 3;     // output tiles of 16: 42 -> 48 matrix rows
+constexpr int kNT = 2;     // position tiles of a wave: two stacked rows x 16 columns
+constexpr int kRing = 4;   // LDS ring slots of one class each
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int bitrev3(int v) { return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1); }
+__host__ __device__ constexpr int iter_of(int cin) { return (cin * KK + kWave - 1) / kWave; }
+__host__ __device__ constexpr int steps_of(int cin) { return (iter_of(cin) + 3) / 4; }          // MFMAs (K = 4) per chain
+__host__ __device__ constexpr int quads_of(int cin) { return (steps_of(cin) * kMT + 3) / 4; }   // 16-byte pieces per lane and class
+__host__ __device__ constexpr int frag_floats(int cin) { return quads_of(cin) * kWave * 4; }
+
+// weights (nset, cout, cin, 5, 5) -> [set][class order index i][quad][lane][4]: element e of quad q is
+// slot s = 4 q + e = 3 m + mt, the A operand of MFMA step m for output tile mt:
+//   lane L holds W[out = 16 mt + (L & 15)][kk = l(i) + 64 (4 m + (L >> 4))]
+// with the causal mask of the output's group applied (pack_weight_kernel's rule), zero past the
+// reduction length, past the last output and in the padding slots.
+__global__ void pack_weight_mfma_kernel(const float *__restrict__ w, float *__restrict__ packed, int cin, int cout,
+                                        int ngroup, int slack, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int quads = quads_of(cin), steps = steps_of(cin), red = cin * KK;
+  const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  long long r = i >> 8;
+  const int quad = (int)(r % quads);
+  r /= quads;
+  const int ci_ = (int)(r & 63), set = (int)(r >> 6);
+  const int slot = quad * 4 + e;
+  float v = 0.f;
+  if (slot < steps * kMT) {
+    const int m = slot / kMT, mt = slot - m * kMT;
+    const int a = ci_ >> 3, b = ci_ & 7;
+    const int l = bitrev3(b) * 8 + bitrev3(a);
+    const int kk = l + kWave * (4 * m + (lane >> 4));
+    const int out = 16 * mt + (lane & 15);
+    if (kk < red && out < cout) {
+      const int tc = out / GO, o = out - tc * GO, group_in = cin / ngroup;
+      const int tap = kk / cin, ci = kk - tap * cin;
+      const int kh = tap / K5, kw = tap - kh * K5;
+      const bool ok = (2 * HALF - kh - kw) * group_in - ci + (tc + slack) * group_in > 0;
+      if (ok) v = w[(((size_t)set * ngroup + tc) * GO + o) * red + ci * KK + tap];
+    }
+  }
+  packed[i] = v;
+}
+
+template <int CIN, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
+    EeGeom g, const int4 *__restrict__ blocks, int rp_n, int ct_n, const float *__restrict__ x, int shared_input,
+    const float *__restrict__ wfrag, const float *__restrict__ bias, const float *__restrict__ slope,
+    const float *__restrict__ residual, float *__restrict__ y, int pad_out, int s_lo, int s_hi) {
+  constexpr int RED = CIN * KK;
+  constexpr int STEPS = steps_of(CIN), QUADS = quads_of(CIN), FRAG = frag_floats(CIN);
+  constexpr int COUT = 3 * (CIN == 14 ? 14 : CIN / 3);  // 3 per group
+  static_assert(COUT <= 16 * kMT, "three output tiles");
+  static_assert(QUADS <= 4, "a class's fragments are four 16-byte pieces per lane at most");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *ring = smem;                 // kRing x FRAG floats
+  float *patch = smem + kRing * FRAG; // (BR + 4) x (BC + 4) x CIN
+  typedef const __attribute__((address_space(4))) int32_t const_i32_t;
+  const_i32_t *brec = (const_i32_t *)(blocks + blockIdx.x);
+  const int tile = brec[0], row0 = brec[1], col0 = brec[2];
+  const int pn = blockIdx.y;  // replica-major image index: set * nimg + img
+  const int set = pn / g.nimg;
+  const int h = g.h, w = g.w;
+  const int BR = 2 * rp_n, BC = 16 * ct_n, PW = BC + 4, PR = BR + 4;
+  const int width = ((const_i32_t *)g.widths)[tile];
+  {
+    // any (position, group) pair of the step range in this block?  (uniform: before any barrier)
+    const int cmax = (col0 + BC < width ? col0 + BC : width) - 1;
+    const int pmin = tile * h + row0 + col0, pmax = tile * h + row0 + BR - 1 + cmax;
+    if (pmax + g.ngroup - 1 < s_lo || pmin >= s_hi) return;
+  }
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  // Weight fragments of class i: 4 KB, one piece per thread (16 bytes with four waves, 8 with eight), staged
+  // through registers (global load at step i - 2, LDS store at step i - 1, first read behind the barrier of step
+  // i).  Not LDS-DMA: the compiler puts a vmcnt(0) in front of every LDS read that follows a DMA it cannot prove
+  // disjoint, i.e. it would wait for the piece it has just requested in every class.  And EVERY thread moves a
+  // piece: behind a guarded load the compiler's wait-count state of the skipped path made it wait for the load
+  // it had just issued.
+  const float *wset = wfrag + (size_t)set * 64 * FRAG;
+  constexpr int PIECE = FRAG / (WAVES * kWave);  // floats per thread and class
+  static_assert(PIECE * WAVES * kWave == FRAG && (PIECE == 4 || PIECE == 2), "whole pieces");
+  typedef float piece_t __attribute__((ext_vector_type(PIECE)));
+  auto fetch_class = [&](int i) { return *reinterpret_cast<const piece_t *>(wset + (size_t)i * FRAG + tid * PIECE); };
+  auto store_class = [&](int i, const piece_t &v) {
+    *reinterpret_cast<piece_t *>(ring + (i & (kRing - 1)) * FRAG + tid * PIECE) = v;
+  };
+  store_class(0, fetch_class(0));
+  piece_t wnext = fetch_class(1);
+  {
+    // the patch: PR rows of PW * CIN contiguous floats each (a pixel is 168 bytes), by LDS-DMA in 16-byte pieces
+    // (8-byte aligned sources: tools/dma16_probe.hip), every piece of the workgroup in flight at once -- a loop of
+    // load / store pairs was a chain of 24 memory round trips, as long as the 64 classes of matrix work.  LDS
+    // piece p = patch row p / row16, piece p % row16 of that row; the tail of the last round re-reads the last
+    // piece into the padding behind the patch.  Columns past the padded row of the buffer (blocks at the right
+    // edge of a full-width tile) repeat its last piece: only dead positions read them.
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    const int xi = shared_input ? pn % g.nimg : pn;
+    const size_t tile_elems = (size_t)(h + 2 * PAD) * (w + 2 * PAD) * CIN;
+    const float *xt = x + ((size_t)xi * g.npart + tile) * tile_elems + ((size_t)row0 * (w + 2 * PAD) + col0) * CIN;
+    const int row16 = PW * CIN / 4;                       // (PW is even: whole pieces)
+    const int lim16 = (w + 2 * PAD - col0) * CIN / 4;     // whole pieces left in the buffer's row
+    const int npiece = PR * row16;
+    const size_t buf_pitch = (size_t)(w + 2 * PAD) * CIN;
+    for (int p0 = 0; p0 < npiece; p0 += WAVES * kWave) {
+      const int p = p0 + tid < npiece ? p0 + tid : npiece - 1;
+      const int pr = p / row16, j = p - pr * row16;
+      const float *src = xt + pr * buf_pitch + 4 * (j < lim16 ? j : lim16 - 1);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)(patch + (size_t)(p0 + wave * kWave) * 4), 16, 0, 0);
+    }
+  }
+  // this wave's positions: rows row0 + 2 rp + {0, 1}, columns col0 + 16 ct + (lane & 15)
+  const int rp = wave % rp_n, ct = wave / rp_n;
+  const int q = lane >> 4;
+  const bool live = col0 + 16 * ct < width;  // (wave-uniform) any live column in its tiles
+  const int lane_base = ((2 * rp) * PW + 16 * ct + (lane & 15)) * CIN;  // window origin of tile 0, in floats
+  const int row_pitch = PW * CIN;
+  const int kh_stride = (PW - K5) * CIN;
+
+  f32x4 S1[kMT * kNT], S2[kMT * kNT], S3[kMT * kNT], P3[kMT * kNT], P4[kMT * kNT], P5[kMT * kNT];
+#pragma unroll
+  for (int t = 0; t < kMT * kNT; t++) S1[t] = S2[t] = S3[t] = P3[t] = P4[t] = P5[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int a = 0; a < 8; a++) {
+    const int la = bitrev3(a);
+    f32x4 Q[kMT * kNT];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int i = a * 8 + b;
+      // class i is in its slot (stored during step i - 1; at i = 0: with the patch); the barrier waits for the LDS
+      // stores only -- __syncthreads() would also wait for the weight load in flight
+      if (a == 0 && b == 0)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the patch DMA of every wave)
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      store_class(i + 1, wnext);         // (slot (i + 1) & 3 was last read in step i - 3; past the end: a dummy)
+      wnext = fetch_class(i + 2 < 64 ? i + 2 : 63);
+      if (!live) continue;  // (wave-uniform; the barriers stay outside)
+      const int l = bitrev3(b) * 8 + la;
+      // A fragments: slot s = 3 m + mt
+      float af[QUADS * 4];
+      {
+        const float4 *fr = reinterpret_cast<const float4 *>(ring + (b & (kRing - 1)) * FRAG) + lane;
+#pragma unroll
+        for (int qd = 0; qd < QUADS; qd++) {
+          const float4 v = fr[qd * kWave];
+          af[4 * qd] = v.x, af[4 * qd + 1] = v.y, af[4 * qd + 2] = v.z, af[4 * qd + 3] = v.w;
+        }
+      }
+      f32x4 acc[kMT * kNT];
+#pragma unroll
+      for (int t = 0; t < kMT * kNT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < STEPS; m++) {
+        // reduction entry of this lane's k row: kk = tap * CIN + ci at window offset (kh, kw); past the end
+        // (zero weights) any finite value will do
+        int kk = l + kWave * (4 * m + q);
+        kk = kk < RED ? kk : RED - 1;
+        const int kh = (kk >= K5 * CIN) + (kk >= 2 * K5 * CIN) + (kk >= 3 * K5 * CIN) + (kk >= 4 * K5 * CIN);
+        const int off = lane_base + kk + kh * kh_stride;
+        const float b0 = patch[off], b1 = patch[off + row_pitch];
+#pragma unroll
+        for (int mt = 0; mt < kMT; mt++) {
+          acc[mt * kNT] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m * kMT + mt], b0, acc[mt * kNT], 0, 0, 0);
+          acc[mt * kNT + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m * kMT + mt], b1, acc[mt * kNT + 1], 0, 0, 0);
+        }
+      }
+      // the butterfly's tree, depth first: as many levels fold as b has trailing ones
+#pragma unroll
+      for (int t = 0; t < kMT * kNT; t++) {
+        if ((b & 1) == 0) {
+          S1[t] = acc[t];
+        } else {
+          const f32x4 u1 = S1[t] + acc[t];  // xor 32
+          if ((b & 2) == 0) {
+            S2[t] = u1;
+          } else {
+            const f32x4 u2 = S2[t] + u1;  // xor 16
+            if ((b & 4) == 0)
+              S3[t] = u2;
+            else
+              Q[t] = S3[t] + u2;  // xor 8
+          }
+        }
+      }
+    }
+    if (live) {
+      // levels xor 4, 2, 1 over the outer index (uniform branches)
+      if ((a & 1) == 0) {
+#pragma unroll
+        for (int t = 0; t < kMT * kNT; t++) P3[t] = Q[t];
+      } else if ((a & 2) == 0) {
+#pragma unroll
+        for (int t = 0; t < kMT * kNT; t++) P4[t] = P3[t] + Q[t];
+      } else if ((a & 4) == 0) {
+#pragma unroll
+        for (int t = 0; t < kMT * kNT; t++) P5[t] = P4[t] + (P3[t] + Q[t]);
+      } else {  // a == 7: the totals (kept in P3)
+#pragma unroll
+        for (int t = 0; t < kMT * kNT; t++) P3[t] = P5[t] + (P4[t] + (P3[t] + Q[t]));
+      }
+    }
+  }
+  if (!live) return;
+  // way out: lane L holds outputs 16 mt + 4 (L >> 4) + r of position (row 2 rp + nt, column L & 15)
+  const int col = col0 + 16 * ct + (lane & 15);
+  if (col >= width) return;
+#pragma unroll
+  for (int nt = 0; nt < kNT; nt++) {
+    const int row = row0 + 2 * rp + nt;
+    const int plane = tile * h + row + col;
+    const size_t ob = ((((size_t)pn * g.npart + tile) * (h + 2 * pad_out) + row + pad_out) * (w + 2 * pad_out) + col + pad_out) * COUT;
+#pragma unroll
+    for (int mt = 0; mt < kMT; mt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int out = 16 * mt + 4 * q + r;
+        const int s = plane + out / GO;
+        if (out < COUT && s >= s_lo && s < s_hi) {
+          float v = P3[mt * kNT + nt][r] + bias[set * COUT + out];
+          if (v < 0) v = v * (slope ? slope[set * COUT + out] : 1.f);
+          if (residual) v = v + residual[ob + out];
+          y[ob + out] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int ee_mfma_packed_floats(int nset, int cin) { return nset * 64 * frag_floats(cin); }
+
+int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
+                        void *stream) {
+  PCONV_REQUIRE(cout == GO * ngroup && cin % ngroup == 0 && (constrain == 5 || constrain == 6) && cout <= 16 * kMT,
+                "ee_pack_weight_mfma: bad layer shape");
+  const long long total = (long long)ee_mfma_packed_floats(nset, cin);
+  hipLaunchKernelGGL(pack_weight_mfma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w,
+                     packed, cin, cout, ngroup, constrain == 5 ? 0 : 1, total);
+  PCONV_LAUNCH_CHECK("ee_pack_weight_mfma");
+  return PCONV_OK;
+}
+
+// rows per tile h must be even; a block is 2 rp_n rows x 16 ct_n columns, rp_n * ct_n = waves of a workgroup
+int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves) {
+  if (cin != 42 || h < 2 || (h & 1)) return 0;
+  static const int wv = getenv("PCONV_EE_MFMA_WAVES") ? atoi(getenv("PCONV_EE_MFMA_WAVES")) : 4;
+  const int nw = wv == 8 ? 8 : 4;
+  int rp = h / 2;
+  const int cap = nw == 8 ? 4 : 2;
+  while (rp > cap || (h / 2) % rp) rp--;
+  *rp_n = rp;
+  *ct_n = nw / rp;
+  *waves = nw;
+  return 1;
+}
+
+int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, const float *x,
+                      int shared_input, const float *wfrag, const float *bias, const float *slope,
+                      const float *residual, float *y, int cin, int cout, int pad_out, int s_lo, int s_hi,
+                      void *stream) {
+  PCONV_REQUIRE(cin == 42 && cout == 42 && g->ngroup == 14, "ee_conv_bulk_mfma: 42 -> 42 channels only");
+  PCONV_REQUIRE(rp_n > 0 && ct_n > 0 && rp_n * ct_n == waves && (waves == 4 || waves == 8) && g->h % (2 * rp_n) == 0,
+                "ee_conv_bulk_mfma: bad block shape");
+  PCONV_REQUIRE(s_lo < s_hi && nblocks > 0, "ee_conv_bulk_mfma: bad range");
+  // ring + patch, the patch rounded up to whole DMA rounds of the workgroup (16 bytes per thread)
+  const size_t round = (size_t)waves * kWave * 16;
+  const size_t patch_bytes = ((size_t)(2 * rp_n + 4) * (16 * ct_n + 4) * 42 * sizeof(float) + round - 1) / round * round;
+  const size_t smem = (size_t)kRing * frag_floats(42) * sizeof(float) + patch_bytes;
+  PCONV_REQUIRE(smem <= 160 * 1024, "ee_conv_bulk_mfma: block needs %zu bytes of LDS", smem);
+  const dim3 grid((unsigned)nblocks, (unsigned)(3 * g->nimg));
+  PCONV_REQUIRE(grid.y <= 65535u, "ee_conv_bulk_mfma: too many images for one launch");
+  auto k4 = ee_conv_bulk_mfma_kernel<42, 4>;
+  auto k8 = ee_conv_bulk_mfma_kernel<42, 8>;
+  {
+    // the dynamic-LDS limit is a per-device attribute of the function (conv.hip)
+    static std::atomic<unsigned long long> raised[2];
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+    const unsigned long long bit = 1ULL << (device & 63);
+    const int kind = waves == 8;
+    if (!(raised[kind].load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(kind ? reinterpret_cast<const void *>(k8) : reinterpret_cast<const void *>(k4),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        pconv_set_error("ee_conv_bulk_mfma: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+        return PCONV_ELAUNCH;
+      }
+      raised[kind].fetch_or(bit, std::memory_order_release);
+    }
+  }
+  if (waves == 8)
+    hipLaunchKernelGGL(k8, grid, dim3(512), smem, as_stream(stream), *g, (const int4 *)blocks, rp_n, ct_n, x, shared_input,
+                       wfrag, bias, slope, residual, y, pad_out, s_lo, s_hi);
+  else
+    hipLaunchKernelGGL(k4, grid, dim3(256), smem, as_stream(stream), *g, (const int4 *)blocks, rp_n, ct_n, x, shared_input,
+                       wfrag, bias, slope, residual, y, pad_out, s_lo, s_hi);
+  PCONV_LAUNCH_CHECK("ee_conv_bulk_mfma");
+  return PCONV_OK;
+}

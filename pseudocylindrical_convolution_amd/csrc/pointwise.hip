@@ -367,6 +367,45 @@ extern "C" int pconv_dquant(const float *x, const float *weight, float *level_ta
   return PCONV_OK;
 }
 
+// ClipData.forward (model_zoo_v2.py:8-26): identity on [0, 1], slope 0.01 outside, as the reference writes it --
+// x * 0.01 below 0, 1 + (x - 1) * 0.01 above 1, every operation rounded on its own (-ffp-contract=off) -- in place,
+// one pass (the reference's masked index assignments are two nonzero() passes with a host synchronisation each).
+__device__ __forceinline__ float leaky_clip(float v) {
+  if (v < 0.f) return v * 0.01f;
+  if (v > 1.f) {
+    const float d = v - 1.f;
+    const float s = d * 0.01f;
+    return 1.f + s;
+  }
+  return v;
+}
+
+__global__ void leaky_clip_kernel(float *__restrict__ x, long long n, int vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    const long long n4 = n / 4;
+    for (long long k = i; k < n4; k += stride) {
+      float4 v = x4[k];
+      v.x = leaky_clip(v.x), v.y = leaky_clip(v.y), v.z = leaky_clip(v.z), v.w = leaky_clip(v.w);
+      x4[k] = v;
+    }
+    for (long long k = n4 * 4 + i; k < n; k += stride) x[k] = leaky_clip(x[k]);
+  } else {
+    for (; i < n; i += stride) x[i] = leaky_clip(x[i]);
+  }
+}
+
+extern "C" int pconv_leaky_clip(float *x, long long n, void *stream) {
+  PCONV_REQUIRE(x && n >= 0, "leaky_clip: bad argument");
+  if (n == 0) return PCONV_OK;
+  const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  hipLaunchKernelGGL(leaky_clip_kernel, dim3(pconv_grid(vec ? (n + 3) / 4 : n)), dim3(kBlock), 0, as_stream(stream), x, n, vec);
+  PCONV_LAUNCH_CHECK("leaky_clip");
+  return PCONV_OK;
+}
+
 extern "C" int pconv_project(const float *in, const float *tf, float *out, int n, int c,
                              int height, int width, int nview, int h_out, int w_out, int nearest,
                              void *stream) {

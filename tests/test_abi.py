@@ -103,6 +103,14 @@ def test_lds_dma_offsets_beyond_32_bits_are_refused():
     rc = lib.pconv_conv2d(dummy, dummy, dummy, dummy, 1, cin, h, w, cout, 3, 1, 0, None, None, 0, None, None, 0, 0,
                           ctypes.addressof(v), None)
     assert rc < 0 and b"32-bit byte offsets" in lib.pconv_last_error()
+    # ... and the output / residual side of the quad ways out (their strides are independent of the input's)
+    big = (1 << 32) // (31 * 4) + 1
+    rows = [[cin * ok_cs, ok_cs, w], [cout * big, big, w - 2], [0, 0, 0], [0, 0, 0]]
+    flat = [x for r in rows for x in r]
+    v = (ctypes.c_longlong * len(flat))(*flat)
+    rc = lib.pconv_conv2d(dummy, dummy, dummy, dummy, 1, cin, h, w, cout, 3, 1, 0, None, None, 0, None, None, 0, 0,
+                          ctypes.addressof(v), None)
+    assert rc < 0 and b"output / residual channel stride" in lib.pconv_last_error()
     # the largest stride of the codec (8 frames at 2048x4096: a 1/2-scale 192-channel tile-batch tensor,
     # channel stride 68 * 2052 floats) is nowhere near the limit
     assert (15 * 68 * 2052 + 67 * 2052 + 2052) * 4 < (1 << 32)

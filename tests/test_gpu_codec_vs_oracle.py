@@ -235,6 +235,17 @@ def test_benchmarked_workload_eight_frames_at_the_metric_size(hip_backend, metri
     if ties == 0:
         assert streams_b[0] == cbytes
         assert (rec_b[:1].cpu() - crec).abs().max().item() < 1e-4
+    # ... and unconditionally: the ORACLE's stream of frame 0 beside the batch's other seven through the same
+    # eight-frame path (four host-driven groups, batched synthesis head) decodes to the oracle's symbols and
+    # reconstructs within the tolerance, whatever the analysis side's ties were
+    mixed = [cbytes] + list(streams_b[1:])
+    dec_m = eng._engine("dec", 16, 512, F).decode(mixed)
+    assert torch.equal(dec_m[:16].cpu(), csym), "the oracle's stream decodes differently inside the batch"
+    assert torch.equal(dec_m[16:], sym_b[16:])
+    rec_m = eng.decode(mixed, H, W)
+    err = (rec_m[:1].cpu() - crec).abs().max().item()
+    assert err < 1e-4, "batched reconstruction of the oracle's stream differs from the oracle by %g" % err
+    assert torch.equal(rec_m[1:], rec_b[1:])
     # bit rates of the eight frames are sane and differ (different content)
     assert len(set(len(s) for s in streams_b)) > 1 and all(len(s) > 1000 for s in streams_b)
 

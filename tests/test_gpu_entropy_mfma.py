@@ -1,0 +1,61 @@
+"""GPU: the encoder's hidden layers on the fp32 matrix cores (csrc/entropy_mfma.hip) write the very streams of the
+vector kernel (PCONV_EE_BULK=valu) -- lane-class sub-GEMMs folded in the butterfly's order are the published
+summation order (entropy.hip), not a new one: no oracle, per-op or step kernel changed.  The whole-codec
+comparisons against the oracle (tests/test_gpu_codec_vs_oracle.py) run on the matrix-core form by default."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ent(seed=7):
+    from pseudocylindrical_convolution_amd import pseudo_codec as PC
+    torch.manual_seed(1234)
+    enc = PC.PseudoEncoder(56, 0)
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in enc.ent.state_dict().items()}
+    enc.ent.load_state_dict(sd)
+    return enc.ent
+
+
+def _encode(ent, sym, h, w, n, mode, monkeypatch, ranges=None):
+    from pseudocylindrical_convolution_amd.engine import EntropyEngine
+    monkeypatch.setenv("PCONV_EE_BULK", mode)
+    if ranges is not None:
+        monkeypatch.setenv("PCONV_ENGINE_ENCODE_RANGES", str(ranges))
+    return EntropyEngine(ent, h, w, n, "cuda:0").encode(sym)
+
+
+@pytest.mark.parametrize("h,w,n", [(2, 64, 1), (4, 128, 2), (8, 256, 1), (16, 512, 1), (2, 80, 3), (6, 96, 1)])
+def test_matrix_core_encoder_writes_the_vector_kernels_streams(hip_backend, monkeypatch, h, w, n):
+    """rows per tile 2 .. 16 (block shapes 2 x 64, 4 x 32), widths that are not multiples of a block, frames in
+    lock-step, and a row count (6) whose blocks are 2 rows high"""
+    ent = _ent()
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(3 + h)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    a = _encode(ent, sym, h, w, n, "valu", monkeypatch)
+    b = _encode(ent, sym, h, w, n, "mfma", monkeypatch)
+    assert a == b
+    assert all(len(s) > 16 for s in b)
+
+
+def test_matrix_core_encoder_in_one_piece_and_in_step_ranges(hip_backend, monkeypatch):
+    """the last group of a call is coded in step ranges (engine.cpp): the matrix-core kernel filters its stores by
+    range and skips blocks outside it; one piece and eight pieces give the same streams as the vector kernel"""
+    ent = _ent(11)
+    h, w, n = 8, 256, 2
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(5)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    ref = _encode(ent, sym, h, w, n, "valu", monkeypatch, ranges=1)
+    for r in (1, 3, 8):
+        assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=r) == ref
+
+
+def test_odd_row_counts_fall_back_to_the_vector_kernel(hip_backend, monkeypatch):
+    ent = _ent()
+    h, w, n = 3, 64, 1
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(9)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch) == _encode(ent, sym, h, w, n, "valu", monkeypatch)

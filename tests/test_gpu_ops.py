@@ -618,3 +618,34 @@ def test_hbm_probe_records_the_gather_kernels(monkeypatch):
     kernels = [r[0] for r in rec.records]
     assert kernels == ["slice_kernel", "uslice_kernel", "dtow2_kernel"]
     assert rec.records[0][2] == 8.0 * x.numel() and all(r[3].elapsed_time(r[4]) > 0 for r in rec.records)
+
+
+def test_leaky_clip_kernel_equals_the_reference_formulation(hip_backend):
+    """ClipData.forward (model_zoo_v2.py:8-26): the one-pass in-place kernel against the reference's masked index
+    assignments, bit for bit (every operation rounds on its own), odd lengths and unaligned views included; the
+    module takes the kernel under no_grad and keeps the autograd formulation otherwise"""
+    from pseudocylindrical_convolution_amd.model_zoo_v2 import ClipData
+    g = torch.Generator().manual_seed(21)
+    for n, off in ((1 << 20, 0), (1000003, 0), (4099, 1), (7, 3)):
+        base = ((torch.rand(n + 8, generator=g) - 0.25) * 2.0)
+        base[:6] = torch.tensor([0.0, 1.0, -0.0, 1.0000001, -1e-30, float("inf")])
+        x = base.cuda()[off:off + n]
+        ref = x.clone()
+        below, above = x < 0, x > 1
+        ref[below] = x[below] * 0.01
+        ref[above] = 1 + (x[above] - 1) * 0.01
+        assert (x.data_ptr() % 16 == 0) == (off == 0)       # off > 0: an unaligned start, the scalar path
+        got = hip_backend.leaky_clip_(x)                     # in place (x is a contiguous view)
+        assert got.data_ptr() == x.data_ptr() and torch.equal(got, ref)
+    x = ((torch.rand(3, 5, 7, generator=g) - 0.25) * 2.0).cuda()
+    with torch.no_grad():
+        y = ClipData()(x)
+    ref = x.clone()
+    ref[x < 0] = x[x < 0] * 0.01
+    ref[x > 1] = 1 + (x[x > 1] - 1) * 0.01
+    assert torch.equal(y, ref) and y.data_ptr() != x.data_ptr()
+    xg = x.clone().requires_grad_(True)
+    yg = ClipData()(xg)
+    assert torch.equal(yg.detach(), ref)
+    yg.sum().backward()
+    assert torch.equal(xg.grad, torch.where((x < 0) | (x > 1), torch.full_like(x, 0.01), torch.ones_like(x)))

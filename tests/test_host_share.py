@@ -86,3 +86,43 @@ def test_bench_emulated_rank_is_pinned_to_its_quota_share(quota_file, monkeypatc
     # a real rank of a real job keeps its whole affinity slice (the quota is shared, not partitioned)
     cores = bench.pin_rank(1, 2)
     assert pinned[-1] == bench.rank_cpus(1, 2) and cores == len(aff) // 2
+
+
+def _plan(lib, nimg):
+    import ctypes
+    v = [ctypes.c_int(-1) for _ in range(4)]
+    assert lib.pconv_ee_host_plan(nimg, *[ctypes.addressof(x) for x in v]) == 0
+    return tuple(x.value for x in v)   # groups, group_threads (0 = one per frame), queued_chain, blocking_sync
+
+
+def test_host_plan_follows_the_share(lib, quota_file, monkeypatch):
+    """one place decides groups / decoding threads / chain / waits (csrc/engine.cpp host_plan).  With CPUs to spare:
+    the measured best of round 3.  On a small share (profiles/round5_host_share.txt): never more driver threads
+    than CPUs, the driver decodes its group's frames alone, host-driven chain, sleeping waits."""
+    for name in ("PCONV_ENGINE_GROUPS", "PCONV_ENGINE_WORKERS", "PCONV_ENGINE_CHAIN", "PCONV_ENGINE_BLOCKING_SYNC"):
+        monkeypatch.delenv(name, raising=False)
+    aff = len(os.sched_getaffinity(0))
+    if aff < 8:
+        pytest.skip("needs 8 CPUs in the affinity mask")
+    quota_file("1600000 100000", local_world=1)          # 16 CPUs (here: min(aff, 16) >= 8)
+    share = min(aff, 16)
+    assert _plan(lib, 1) == (1, 0, 1, 0)                 # one frame: one group, queued chain
+    assert _plan(lib, 2) == (2, 0, 1, 0)
+    assert _plan(lib, 4) == (2, 0, 1, 0)
+    if share >= 9:
+        assert _plan(lib, 8) == (4, 0, 0, 0)             # the benchmark's 8 frames: four host-driven groups of two
+    quota_file("1600000 100000", local_world=4)          # 4 CPUs per rank
+    assert _plan(lib, 8) == (4, 1, 0, 1)                 # four drivers, each decodes its two frames itself, waits sleep
+    assert _plan(lib, 2) == (2, 0, 1, 0)                 # two frames still fit (2 + 1 <= 4)
+    quota_file("1600000 100000", local_world=8)          # 2 CPUs per rank
+    assert _plan(lib, 8) == (2, 1, 0, 1)                 # two groups of four
+    assert _plan(lib, 2) == (2, 1, 0, 1)                 # 2 + 1 > 2: host-driven, no queueing thread beside the poller
+    assert _plan(lib, 1) == (1, 0, 1, 0)
+    quota_file("1600000 100000", local_world=16)         # 1 CPU
+    assert _plan(lib, 8) == (1, 1, 0, 1)
+    # the knobs still win
+    monkeypatch.setenv("PCONV_ENGINE_GROUPS", "4")
+    monkeypatch.setenv("PCONV_ENGINE_WORKERS", "2")
+    monkeypatch.setenv("PCONV_ENGINE_CHAIN", "queued")
+    monkeypatch.setenv("PCONV_ENGINE_BLOCKING_SYNC", "0")
+    assert _plan(lib, 8) == (4, 2, 1, 0)
