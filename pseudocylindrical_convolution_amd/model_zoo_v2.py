@@ -27,7 +27,7 @@ class _LeakyClip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         ops = backend.ops()
-        if x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad) and hasattr(ops, "leaky_clip_"):
+        if x.is_cuda and not ctx.needs_input_grad[0] and hasattr(ops, "leaky_clip_"):  # (grad mode is off in here)
             # the codec path: one in-place pass of a hand-written kernel over a copy (the same three roundings;
             # the masked assignments below are two nonzero() passes with a host synchronisation each)
             return ops.leaky_clip_(x.detach().clone().contiguous())
