@@ -57,7 +57,8 @@ def winograd_gain(kernel):
             return gain
     return 1.0
 MODEL_VALID_DIM = 56                 # model-idx 3 of the --ssim list (pseudo_codec.py:18-19)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("round4_bench_pmc.json", "round3_bench_pmc.json", "round2_bench_pmc.json")]
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("round5_bench_pmc.json", "round4_bench_pmc.json", "round3_bench_pmc.json",
+                                                             "round2_bench_pmc.json")]
 
 
 # ----------------------------------------------------------------------------
@@ -281,8 +282,15 @@ def hbm_table(per_kernel):
                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
         rec, path = _pmc_record(kernel)
         if rec and rec.get("hbm_bytes_per_launch") is not None:
-            row["traffic"] = int(rec["hbm_bytes_per_launch"])
-            row["traffic_source"] = "profiles/%s" % os.path.basename(path)
+            # counted bytes per launch of the --pmc pass, rescaled to THIS run's launch size by the algorithmic
+            # bytes (the same kernel over another number of frames); a summary without the pass's algorithmic
+            # bytes (rounds 2-4: taken at 2 frames per GPU) cannot be rescaled and is not quoted as this run's
+            if rec.get("algorithmic_bytes_per_launch"):
+                row["traffic"] = int(rec["hbm_bytes_per_launch"] * (d["flops"] / n) / rec["algorithmic_bytes_per_launch"])
+                row["traffic_source"] = "profiles/%s" % os.path.basename(path)
+            else:
+                row["traffic_at_pmc_launch_size"] = int(rec["hbm_bytes_per_launch"])
+                row["traffic_source"] = "profiles/%s (launches of another size: not rescaled)" % os.path.basename(path)
         worst = max(d["classes"].items(), key=lambda kv: kv[1][1])
         row["largest_class"] = {"class": worst[0], "launches": worst[1][2],
                                 "avg_launch_us": round(worst[1][1] / worst[1][2] * 1e6, 2),

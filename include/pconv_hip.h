@@ -448,6 +448,12 @@ int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream)
  * `symbols` must stay alive until end.  Between the two the caller may queue other GPU work in
  * `stream` (the transforms of the next frames): it runs while the CPU codes. */
 int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *stream);
+/* The last group of an encode call is evaluated in `nrange` wavefront step ranges (1 .. 8; 0 = the default: 4, or
+ * PCONV_ENGINE_ENCODE_RANGES), each range's CDF rows copied to the host as soon as they exist, so that the
+ * arithmetic coder starts before the GPU has finished the group.  A caller that pipelines several encode calls
+ * (engine.CodecEngine.encode: chunk k is coded on the CPU under chunk k + 1's GPU work) asks for 1 on all but the
+ * last: ranges re-evaluate the blocks on their boundaries.  Same streams for every value. */
+int pconv_ee_set_encode_ranges(pconv_entropy_engine *e, int nrange);
 int pconv_ee_encode_end(pconv_entropy_engine *e, void *stream);
 const uint8_t *pconv_ee_stream(const pconv_entropy_engine *e, int img, size_t *nbytes);
 int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, const size_t *nbytes,

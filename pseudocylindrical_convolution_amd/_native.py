@@ -86,6 +86,7 @@ _HIP_SIGNATURES = {
     "pconv_ee_host_plan": [I, P, P, P, P],
     "pconv_ee_encode": [P, P, P],
     "pconv_ee_encode_begin": [P, P, P],
+    "pconv_ee_set_encode_ranges": [P, I],
     "pconv_ee_encode_end": [P, P],
     "pconv_ee_decode": [P, P, P, P, P],
 }

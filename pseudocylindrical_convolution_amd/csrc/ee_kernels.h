@@ -82,14 +82,14 @@ int ee_conv_bulk(const EeGeom *g, const float *x, int shared_input, const float 
 // (first_idx, n_idx, s_lo, s_hi: only the (position, group) pairs of the wavefront steps [s_lo, s_hi), found among
 // the schedule entries first_idx .. first_idx + n_idx - 1; the whole schedule: 0, npos, 0, INT_MAX)
 // The same layer on the fp32 matrix cores (entropy_mfma.hip), identical bits: 42 -> 42 channels (14 groups),
-// even rows per tile.  ee_mfma_block_shape: 1 and the block shape (2 rp_n rows x 16 ct_n columns per workgroup of
-// `waves` waves) when the kernel takes the layer, else 0.  blocks: device int4 records (tile, first row, first
+// ee_mfma_block_shape: 1 and the block shape (nt rp_n rows x 16 ct_n columns per workgroup of
+// `waves` waves, nt = 1 or 2 rows per wave) when the kernel takes the layer, else 0.  blocks: device int4 records (tile, first row, first
 // column, 0) covering every live position; wfrag: ee_pack_weight_mfma's fragments (ee_mfma_packed_floats floats).
-int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves);
+int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves, int *nt);
 int ee_mfma_packed_floats(int nset, int cin);
 int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
                         void *stream);
-int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, const float *x,
+int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, int nt, const float *x,
                       int shared_input, const float *wfrag, const float *bias, const float *slope,
                       const float *residual, float *y, int cin, int cout, int pad_out, int s_lo, int s_hi,
                       void *stream);

@@ -32,6 +32,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -307,12 +308,18 @@ struct pconv_entropy_engine {
   float *vh_wgt = nullptr;
   int32_t *pos_plane_d = nullptr;
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
+  int encode_ranges = -1;         // step ranges of a call's last group (pconv_ee_set_encode_ranges); -1: the default
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
   // matrix-core form of the encoder's hidden layers (entropy_mfma.hip): weights as MFMA fragments, the list of
   // position blocks; mfma_waves == 0: not available for this shape (the vector kernel takes every layer)
   float *lwf[kLayers] = {nullptr};
   void *mfma_blocks_d = nullptr;
-  int mfma_nblocks = 0, mfma_rp = 0, mfma_ct = 0, mfma_waves = 0;
+  int mfma_nblocks = 0, mfma_rp = 0, mfma_ct = 0, mfma_waves = 0, mfma_nt = 0;
+  std::vector<int32_t> mfma_blocks_h;  // (tile, first row, first column, 0) per block
+  // blocks that hold a (position, group) pair of a step range, compacted (a launch over ALL blocks whose
+  // out-of-range workgroups exit at once still took 0.75 of a full launch: r5, profiles/round5_entropy_mfma_*.txt)
+  std::map<std::pair<int, int>, std::pair<void *, int>> mfma_range_blocks;
+  std::mutex mfma_range_mu;
   const float *lb[kLayers] = {nullptr}, *la[kLayers] = {nullptr};
   bool bound[kLayers] = {false};
   std::vector<Group> groups;
@@ -501,21 +508,22 @@ struct pconv_entropy_engine {
     {
       // PCONV_EE_BULK=valu keeps the vector kernel for every layer of the encoder (A/B; identical streams)
       const char *env = getenv("PCONV_EE_BULK");
-      int rp = 0, ct = 0, wv = 0;
-      if (!(env && env[0] == 'v') && ngroup == 14 && ee_mfma_block_shape(h, 3 * ngroup, &rp, &ct, &wv)) {
+      int rp = 0, ct = 0, wv = 0, nt = 0;
+      if (!(env && env[0] == 'v') && ngroup == 14 && ee_mfma_block_shape(h, 3 * ngroup, &rp, &ct, &wv, &nt)) {
         std::vector<int32_t> blk;
         for (int t = 0; t < npart; t++)
-          for (int r0 = 0; r0 < h; r0 += 2 * rp)
+          for (int r0 = 0; r0 < h; r0 += nt * rp)
             for (int c0 = 0; c0 < widths[t]; c0 += 16 * ct) {
               const int32_t rec[4] = {t, r0, c0, 0};
               blk.insert(blk.end(), rec, rec + 4);
             }
+        mfma_blocks_h = blk;
         if (!blk.empty()) {
           HIP_TRY(hipMalloc(&mfma_blocks_d, blk.size() * 4));
           HIP_TRY(hipMemcpy(mfma_blocks_d, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
           for (int l = 1; l < kLayers; l++) HIP_TRY(hipMalloc(&lwf[l], (size_t)ee_mfma_packed_floats(3, 3 * ngroup) * 4));
           mfma_nblocks = (int)(blk.size() / 4);
-          mfma_rp = rp, mfma_ct = ct, mfma_waves = wv;
+          mfma_rp = rp, mfma_ct = ct, mfma_waves = wv, mfma_nt = nt;
         }
       }
     }
@@ -545,6 +553,7 @@ struct pconv_entropy_engine {
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
     for (int l = 0; l < kLayers; l++) freed(lwf[l]);
     freed(mfma_blocks_d);
+    for (auto &kv : mfma_range_blocks) freed(kv.second.first);
     for (Group &g : groups) {
       freed(g.ctx); freed(g.tables_d); freed(g.labels_d); freed(g.step_row_d);
       for (int l = 0; l < kLayers; l++) freed(g.act[l]);
@@ -624,6 +633,38 @@ struct pconv_entropy_engine {
     *count = p_hi > p_lo ? sched_start[p_hi] - sched_start[p_lo] : 0;
   }
 
+  // the blocks of the matrix-core kernel that hold a pair of the steps [s_lo, s_hi) (entropy_mfma.hip's own test:
+  // planes pmin .. pmax of the block, groups 0 .. ngroup - 1), as a device list; built once per range
+  int mfma_blocks_of_range(int s_lo, int s_hi, const void **list, int *count) {
+    if (s_lo <= 0 && s_hi >= nsteps) {
+      *list = mfma_blocks_d;
+      *count = mfma_nblocks;
+      return PCONV_OK;
+    }
+    std::lock_guard<std::mutex> lk(mfma_range_mu);
+    auto it = mfma_range_blocks.find({s_lo, s_hi});
+    if (it == mfma_range_blocks.end()) {
+      std::vector<int32_t> act;
+      const int br = mfma_nt * mfma_rp, bc = 16 * mfma_ct;
+      for (size_t k = 0; k + 3 < mfma_blocks_h.size(); k += 4) {
+        const int t = mfma_blocks_h[k], r0 = mfma_blocks_h[k + 1], c0 = mfma_blocks_h[k + 2];
+        const int cmax = std::min(c0 + bc, (int)widths[t]) - 1;
+        const int pmin = t * h + r0 + c0, pmax = t * h + r0 + br - 1 + cmax;
+        if (pmax + ngroup - 1 < s_lo || pmin >= s_hi) continue;
+        act.insert(act.end(), mfma_blocks_h.begin() + k, mfma_blocks_h.begin() + k + 4);
+      }
+      void *d = nullptr;
+      if (!act.empty()) {
+        HIP_TRY(hipMalloc(&d, act.size() * 4));
+        HIP_TRY(hipMemcpy(d, act.data(), act.size() * 4, hipMemcpyHostToDevice));
+      }
+      it = mfma_range_blocks.emplace(std::make_pair(s_lo, s_hi), std::make_pair(d, (int)(act.size() / 4))).first;
+    }
+    *list = it->second.first;
+    *count = it->second.second;
+    return PCONV_OK;
+  }
+
   // every layer once over the (plane, group) pairs of the steps [s_lo, s_hi): the encoder knows all symbols.  A
   // pair's unmasked inputs lie in steps <= its own (masks of constrain 5 / 6), i.e. in this range's previous
   // layer or in an earlier range: ranges are evaluated in step order, layer by layer inside a range; what a
@@ -632,11 +673,15 @@ struct pconv_entropy_engine {
     const int hid = 3 * ngroup;
     int first = 0, count = 0;
     step_range_entries(s_lo, s_hi, &first, &count);
+    const void *blist = nullptr;
+    int nblist = 0;
+    if (mfma_waves) PC_TRY(mfma_blocks_of_range(s_lo, s_hi, &blist, &nblist));
     for (int l = 0; l < kLayers; l++) {
       const float *in = (l == 0) ? g.ctx : g.act[l - 1];
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
+      if (mfma_waves && lwf[l] && nblist == 0) continue;  // (no block of this range: nothing to evaluate)
       if (mfma_waves && lwf[l])
-        PC_TRY(ee_conv_bulk_mfma(&g.geom, mfma_blocks_d, mfma_nblocks, mfma_rp, mfma_ct, mfma_waves, in, 0, lwf[l], lb[l],
+        PC_TRY(ee_conv_bulk_mfma(&g.geom, blist, nblist, mfma_rp, mfma_ct, mfma_waves, mfma_nt, in, 0, lwf[l], lb[l],
                                  la[l], res, g.act[l], layer_cin(l), hid, l == kLayers - 1 ? 0 : kPad, s_lo, s_hi,
                                  g.stream));
       else
@@ -857,6 +902,16 @@ int pconv_ee_host_plan(int nimg, int *groups, int *group_threads, int *queued_ch
   return PCONV_OK;
 }
 
+// step ranges the LAST group of the following encode calls is evaluated in (1: one piece; 0: back to the default,
+// 4 or PCONV_ENGINE_ENCODE_RANGES).  Ranges buy an earlier start of the arithmetic coder at the price of a second
+// evaluation of the blocks on the range boundaries: worth it only for the encode whose coding nothing else hides
+// (the last chunk of a pipelined CodecEngine.encode).
+int pconv_ee_set_encode_ranges(pconv_entropy_engine *e, int nrange) {
+  PCONV_REQUIRE(e && nrange >= 0 && nrange <= kMaxEncodeRanges, "ee_set_encode_ranges: bad argument");
+  e->encode_ranges = nrange > 0 ? nrange : -1;
+  return PCONV_OK;
+}
+
 long long pconv_ee_symbols_per_image(const pconv_entropy_engine *e) { return e ? (long long)e->sym_per_img : -1; }
 int pconv_ee_steps(const pconv_entropy_engine *e) { return e ? e->nsteps : -1; }
 
@@ -880,7 +935,8 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
   // first group's tables are on the host half-way and its frames are coded on the CPU while
   // the GPU works on the second group and on what the caller queues after this call.
   // PCONV_ENGINE_ENCODE_RANGES: step ranges of the call's last group (default 4; 1 = as one piece)
-  const int last_ranges = getenv("PCONV_ENGINE_ENCODE_RANGES") ? atoi(getenv("PCONV_ENGINE_ENCODE_RANGES")) : 4;
+  const int last_ranges = e->encode_ranges > 0 ? e->encode_ranges
+                          : (getenv("PCONV_ENGINE_ENCODE_RANGES") ? atoi(getenv("PCONV_ENGINE_ENCODE_RANGES")) : 4);
   for (size_t k = 0; k < e->groups.size(); k++) {
     Group &g = e->groups[k];
     e->set_encode_ranges(g, (k + 1 == e->groups.size() && !e->stepwise_encoder) ? last_ranges : 1);

@@ -41,8 +41,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr int K5 = 5, KK = 25, HALF = 2, PAD = 2, GO = 3;
 constexpr int kMT = 3;     // output tiles of 16: 42 -> 48 matrix rows
-constexpr int kNT = 2;     // position tiles of a wave: two stacked rows x 16 columns
 constexpr int kRing = 4;   // LDS ring slots of one class each
+constexpr int kPatchSlack = 256;  // floats behind the patch that entries past the reduction length may read
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int bitrev3(int v) { return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1); }
@@ -85,8 +85,10 @@ __global__ void pack_weight_mfma_kernel(const float *__restrict__ w, float *__re
   packed[i] = v;
 }
 
-template <int CIN, int WAVES>
-__global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
+// kNT: position tiles of a wave = stacked rows x 16 columns.  2: every weight fragment feeds two MFMAs, 250
+// registers, two waves per SIMD; 1: 15 MFMAs per class and wave, <= 168 registers, three waves per SIMD
+template <int CIN, int WAVES, int kNT>
+__global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_mfma_kernel(
     EeGeom g, const int4 *__restrict__ blocks, int rp_n, int ct_n, const float *__restrict__ x, int shared_input,
     const float *__restrict__ wfrag, const float *__restrict__ bias, const float *__restrict__ slope,
     const float *__restrict__ residual, float *__restrict__ y, int pad_out, int s_lo, int s_hi) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
   const int pn = blockIdx.y;  // replica-major image index: set * nimg + img
   const int set = pn / g.nimg;
   const int h = g.h, w = g.w;
-  const int BR = 2 * rp_n, BC = 16 * ct_n, PW = BC + 4, PR = BR + 4;
+  const int BR = kNT * rp_n, BC = 16 * ct_n, PW = BC + 4, PR = BR + 4;
   const int width = ((const_i32_t *)g.widths)[tile];
   {
     // any (position, group) pair of the step range in this block?  (uniform: before any barrier)
@@ -128,8 +130,12 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
   auto store_class = [&](int i, const piece_t &v) {
     *reinterpret_cast<piece_t *>(ring + (i & (kRing - 1)) * FRAG + tid * PIECE) = v;
   };
+  // PIPE (one row per wave: registers to spare): the operands of class i + 1 are read from LDS while the matrix
+  // instructions of class i run, so the weight ring runs one class further ahead
+  constexpr bool PIPE = kNT == 1;
   store_class(0, fetch_class(0));
-  piece_t wnext = fetch_class(1);
+  if (PIPE) store_class(1, fetch_class(1));
+  piece_t wnext = fetch_class(PIPE ? 2 : 1);
   {
     // the patch: PR rows of PW * CIN contiguous floats each (a pixel is 168 bytes), by LDS-DMA in 16-byte pieces
     // (8-byte aligned sources: tools/dma16_probe.hip), every piece of the workgroup in flight at once -- a loop of
@@ -152,19 +158,60 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
       const float *src = xt + pr * buf_pitch + 4 * (j < lim16 ? j : lim16 - 1);
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)(patch + (size_t)(p0 + wave * kWave) * 4), 16, 0, 0);
     }
+    // the slack behind the (rounded) patch that over-long entries of the last rows may read
+    const int rounded = (npiece + WAVES * kWave - 1) / (WAVES * kWave) * (WAVES * kWave) * 4;
+    for (int k = tid; k < kPatchSlack; k += WAVES * kWave) patch[rounded + k] = 0.f;
   }
-  // this wave's positions: rows row0 + 2 rp + {0, 1}, columns col0 + 16 ct + (lane & 15)
+  // this wave's positions: rows row0 + kNT rp + {0 .. kNT - 1}, columns col0 + 16 ct + (lane & 15)
   const int rp = wave % rp_n, ct = wave / rp_n;
   const int q = lane >> 4;
   const bool live = col0 + 16 * ct < width;  // (wave-uniform) any live column in its tiles
-  const int lane_base = ((2 * rp) * PW + 16 * ct + (lane & 15)) * CIN;  // window origin of tile 0, in floats
+  const int lane_base = ((kNT * rp) * PW + 16 * ct + (lane & 15)) * CIN;  // window origin of tile 0, in floats
   const int row_pitch = PW * CIN;
   const int kh_stride = (PW - K5) * CIN;
+  // Byte offset of reduction entry kk = l + 64 (4 m + q) of this lane's window: 4 (lane_base + kk + kh * kh_stride),
+  // kh = kk / (5 CIN) the window row.  While the class l runs over 0 .. 63 an entry's row changes at most once
+  // (64 < 5 CIN), at l = thr[m] (64: never): off = base[m] + 4 l (+ 4 kh_stride from thr[m] on) -- a compare, a
+  // select and an add per MFMA step instead of a division by 210.  Entries past the reduction length (zero
+  // weights: any finite value will do) stay in window row 4 and run at most 230 floats past the window's end:
+  // into the patch's following rows or the zeroed kPatchSlack behind it.
+  unsigned base_b[STEPS];
+  int thr[STEPS];
+#pragma unroll
+  for (int m = 0; m < STEPS; m++) {
+    const int c = kWave * (4 * m + q);
+    int kh0 = c / (K5 * CIN);
+    kh0 = kh0 < K5 - 1 ? kh0 : K5 - 1;
+    const int cross = (kh0 + 1) * K5 * CIN - c;  // first l in the next window row
+    thr[m] = (kh0 < K5 - 1 && cross < kWave) ? cross : kWave;
+    base_b[m] = 4u * (unsigned)(lane_base + c + kh0 * kh_stride);
+  }
 
   f32x4 S1[kMT * kNT], S2[kMT * kNT], S3[kMT * kNT], P3[kMT * kNT], P4[kMT * kNT], P5[kMT * kNT];
 #pragma unroll
   for (int t = 0; t < kMT * kNT; t++) S1[t] = S2[t] = S3[t] = P3[t] = P4[t] = P5[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // operands of a class: A fragments (slot s = 3 m + mt of the ring slot) and this lane's B entries of the patch
+  auto read_operands = [&](int slot, int l, float (&af)[QUADS * 4], float (&bf)[STEPS][kNT]) {
+    const float4 *fr = reinterpret_cast<const float4 *>(ring + slot * FRAG) + lane;
+#pragma unroll
+    for (int qd = 0; qd < QUADS; qd++) {
+      const float4 v = fr[qd * kWave];
+      af[4 * qd] = v.x, af[4 * qd + 1] = v.y, af[4 * qd + 2] = v.z, af[4 * qd + 3] = v.w;
+    }
+#pragma unroll
+    for (int m = 0; m < STEPS; m++) {
+      const unsigned off = base_b[m] + 4u * (unsigned)l + (l >= thr[m] ? 4u * (unsigned)kh_stride : 0u);
+#pragma unroll
+      for (int nt = 0; nt < kNT; nt++)
+        bf[m][nt] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(patch) + off + nt * 4 * row_pitch);
+    }
+  };
+  float af[QUADS * 4], bf[STEPS][kNT];
+  if (PIPE) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the patch DMA, classes 0 and 1
+    if (live) read_operands(0, 0, af, bf);
+  }
 #pragma unroll 1
   for (int a = 0; a < 8; a++) {
     const int la = bitrev3(a);
@@ -172,43 +219,45 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const int i = a * 8 + b;
-      // class i is in its slot (stored during step i - 1; at i = 0: with the patch); the barrier waits for the LDS
-      // stores only -- __syncthreads() would also wait for the weight load in flight
-      if (a == 0 && b == 0)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the patch DMA of every wave)
-      else
+      float afn[QUADS * 4], bfn[STEPS][kNT];
+      if (PIPE) {
+        // class i + 1 is in its slot (stored during step i - 1); the barrier waits for the LDS stores only --
+        // __syncthreads() would also wait for the weight load in flight
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      store_class(i + 1, wnext);         // (slot (i + 1) & 3 was last read in step i - 3; past the end: a dummy)
-      wnext = fetch_class(i + 2 < 64 ? i + 2 : 63);
-      if (!live) continue;  // (wave-uniform; the barriers stay outside)
-      const int l = bitrev3(b) * 8 + la;
-      // A fragments: slot s = 3 m + mt
-      float af[QUADS * 4];
-      {
-        const float4 *fr = reinterpret_cast<const float4 *>(ring + (b & (kRing - 1)) * FRAG) + lane;
-#pragma unroll
-        for (int qd = 0; qd < QUADS; qd++) {
-          const float4 v = fr[qd * kWave];
-          af[4 * qd] = v.x, af[4 * qd + 1] = v.y, af[4 * qd + 2] = v.z, af[4 * qd + 3] = v.w;
-        }
+        store_class(i + 2, wnext);  // (slot (i + 2) & 3 was last read in step i - 3; past the end: a dummy)
+        wnext = fetch_class(i + 3 < 64 ? i + 3 : 63);
+        if (!live) continue;  // (wave-uniform; the barriers stay outside)
+        // the next class's operands, in flight under this class's matrix instructions
+        const int ln = b < 7 ? bitrev3(b + 1) * 8 + la : bitrev3((a + 1) & 7);
+        read_operands((b + 1) & (kRing - 1), ln, afn, bfn);  // (behind the last class: a dummy)
+      } else {
+        // class i is in its slot (stored during step i - 1; at i = 0: with the patch)
+        if (a == 0 && b == 0)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the patch DMA of every wave)
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        store_class(i + 1, wnext);  // (slot (i + 1) & 3 was last read in step i - 3; past the end: a dummy)
+        wnext = fetch_class(i + 2 < 64 ? i + 2 : 63);
+        if (!live) continue;
+        read_operands(b & (kRing - 1), bitrev3(b) * 8 + la, af, bf);
       }
       f32x4 acc[kMT * kNT];
 #pragma unroll
       for (int t = 0; t < kMT * kNT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < STEPS; m++) {
-        // reduction entry of this lane's k row: kk = tap * CIN + ci at window offset (kh, kw); past the end
-        // (zero weights) any finite value will do
-        int kk = l + kWave * (4 * m + q);
-        kk = kk < RED ? kk : RED - 1;
-        const int kh = (kk >= K5 * CIN) + (kk >= 2 * K5 * CIN) + (kk >= 3 * K5 * CIN) + (kk >= 4 * K5 * CIN);
-        const int off = lane_base + kk + kh * kh_stride;
-        const float b0 = patch[off], b1 = patch[off + row_pitch];
+      for (int m = 0; m < STEPS; m++)
 #pragma unroll
-        for (int mt = 0; mt < kMT; mt++) {
-          acc[mt * kNT] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m * kMT + mt], b0, acc[mt * kNT], 0, 0, 0);
-          acc[mt * kNT + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m * kMT + mt], b1, acc[mt * kNT + 1], 0, 0, 0);
-        }
+        for (int mt = 0; mt < kMT; mt++)
+#pragma unroll
+          for (int nt = 0; nt < kNT; nt++)
+            acc[mt * kNT + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m * kMT + mt], bf[m][nt], acc[mt * kNT + nt], 0, 0, 0);
+      if (PIPE) {
+#pragma unroll
+        for (int k = 0; k < QUADS * 4; k++) af[k] = afn[k];
+#pragma unroll
+        for (int m = 0; m < STEPS; m++)
+#pragma unroll
+          for (int nt = 0; nt < kNT; nt++) bf[m][nt] = bfn[m][nt];
       }
       // the butterfly's tree, depth first: as many levels fold as b has trailing ones
 #pragma unroll
@@ -252,7 +301,7 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma_kernel(
   if (col >= width) return;
 #pragma unroll
   for (int nt = 0; nt < kNT; nt++) {
-    const int row = row0 + 2 * rp + nt;
+    const int row = row0 + kNT * rp + nt;
     const int plane = tile * h + row + col;
     const size_t ob = ((((size_t)pn * g.npart + tile) * (h + 2 * pad_out) + row + pad_out) * (w + 2 * pad_out) + col + pad_out) * COUT;
 #pragma unroll
@@ -287,46 +336,57 @@ int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int c
   return PCONV_OK;
 }
 
-// rows per tile h must be even; a block is 2 rp_n rows x 16 ct_n columns, rp_n * ct_n = waves of a workgroup
-int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves) {
-  if (cin != 42 || h < 2 || (h & 1)) return 0;
+// a block is nt * rp_n rows x 16 ct_n columns, rp_n * ct_n = waves of a workgroup, nt = rows of a wave (1 or 2;
+// PCONV_EE_MFMA_NT); rows per tile must be a multiple of nt * rp_n
+int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves, int *nt) {
   static const int wv = getenv("PCONV_EE_MFMA_WAVES") ? atoi(getenv("PCONV_EE_MFMA_WAVES")) : 4;
+  // measured (MI355X, 4096x2048, one frame x 3 sets per launch, profiles/round5_entropy_mfma_variants.txt): one row per
+  // wave 452 us per full launch (two rows: 474; eight waves per workgroup: 509 / 550), 591 / 715 us for a frame
+  // in four step ranges
+  static const int nt_env = getenv("PCONV_EE_MFMA_NT") ? atoi(getenv("PCONV_EE_MFMA_NT")) : 1;
   const int nw = wv == 8 ? 8 : 4;
-  int rp = h / 2;
-  const int cap = nw == 8 ? 4 : 2;
-  while (rp > cap || (h / 2) % rp) rp--;
+  const int n = (nt_env == 1 || (h & 1)) ? 1 : 2;
+  if (cin != 42 || h < n) return 0;
+  const int rows = h / n;  // wave rows per tile
+  int rp = rows;
+  const int cap = nw == 8 ? 4 : (n == 1 ? 4 : 2);
+  while (rp > cap || rows % rp || nw % rp) rp--;
   *rp_n = rp;
   *ct_n = nw / rp;
   *waves = nw;
+  *nt = n;
   return 1;
 }
 
-int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, const float *x,
+int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, int nt, const float *x,
                       int shared_input, const float *wfrag, const float *bias, const float *slope,
                       const float *residual, float *y, int cin, int cout, int pad_out, int s_lo, int s_hi,
                       void *stream) {
   PCONV_REQUIRE(cin == 42 && cout == 42 && g->ngroup == 14, "ee_conv_bulk_mfma: 42 -> 42 channels only");
-  PCONV_REQUIRE(rp_n > 0 && ct_n > 0 && rp_n * ct_n == waves && (waves == 4 || waves == 8) && g->h % (2 * rp_n) == 0,
+  PCONV_REQUIRE(rp_n > 0 && ct_n > 0 && rp_n * ct_n == waves && (waves == 4 || waves == 8) && (nt == 1 || nt == 2) &&
+                    g->h % (nt * rp_n) == 0,
                 "ee_conv_bulk_mfma: bad block shape");
   PCONV_REQUIRE(s_lo < s_hi && nblocks > 0, "ee_conv_bulk_mfma: bad range");
   // ring + patch, the patch rounded up to whole DMA rounds of the workgroup (16 bytes per thread)
   const size_t round = (size_t)waves * kWave * 16;
-  const size_t patch_bytes = ((size_t)(2 * rp_n + 4) * (16 * ct_n + 4) * 42 * sizeof(float) + round - 1) / round * round;
-  const size_t smem = (size_t)kRing * frag_floats(42) * sizeof(float) + patch_bytes;
+  const size_t patch_bytes = ((size_t)(nt * rp_n + 4) * (16 * ct_n + 4) * 42 * sizeof(float) + round - 1) / round * round;
+  const size_t smem = (size_t)kRing * frag_floats(42) * sizeof(float) + patch_bytes + kPatchSlack * sizeof(float);
   PCONV_REQUIRE(smem <= 160 * 1024, "ee_conv_bulk_mfma: block needs %zu bytes of LDS", smem);
   const dim3 grid((unsigned)nblocks, (unsigned)(3 * g->nimg));
   PCONV_REQUIRE(grid.y <= 65535u, "ee_conv_bulk_mfma: too many images for one launch");
-  auto k4 = ee_conv_bulk_mfma_kernel<42, 4>;
-  auto k8 = ee_conv_bulk_mfma_kernel<42, 8>;
+  typedef void (*kernel_t)(EeGeom, const int4 *, int, int, const float *, int, const float *, const float *, const float *,
+                           const float *, float *, int, int, int);
+  const int kind = (waves == 8 ? 2 : 0) + (nt == 1 ? 1 : 0);
+  static const kernel_t kernels[4] = {ee_conv_bulk_mfma_kernel<42, 4, 2>, ee_conv_bulk_mfma_kernel<42, 4, 1>,
+                                      ee_conv_bulk_mfma_kernel<42, 8, 2>, ee_conv_bulk_mfma_kernel<42, 8, 1>};
   {
     // the dynamic-LDS limit is a per-device attribute of the function (conv.hip)
-    static std::atomic<unsigned long long> raised[2];
+    static std::atomic<unsigned long long> raised[4];
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) device = 0;
     const unsigned long long bit = 1ULL << (device & 63);
-    const int kind = waves == 8;
     if (!(raised[kind].load(std::memory_order_acquire) & bit)) {
-      hipError_t e = hipFuncSetAttribute(kind ? reinterpret_cast<const void *>(k8) : reinterpret_cast<const void *>(k4),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernels[kind]),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
         pconv_set_error("ee_conv_bulk_mfma: cannot raise dynamic LDS: %s", hipGetErrorString(e));
@@ -335,12 +395,8 @@ int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n
       raised[kind].fetch_or(bit, std::memory_order_release);
     }
   }
-  if (waves == 8)
-    hipLaunchKernelGGL(k8, grid, dim3(512), smem, as_stream(stream), *g, (const int4 *)blocks, rp_n, ct_n, x, shared_input,
-                       wfrag, bias, slope, residual, y, pad_out, s_lo, s_hi);
-  else
-    hipLaunchKernelGGL(k4, grid, dim3(256), smem, as_stream(stream), *g, (const int4 *)blocks, rp_n, ct_n, x, shared_input,
-                       wfrag, bias, slope, residual, y, pad_out, s_lo, s_hi);
+  hipLaunchKernelGGL(kernels[kind], grid, dim3(waves * kWave), smem, as_stream(stream), *g, (const int4 *)blocks, rp_n, ct_n, x,
+                     shared_input, wfrag, bias, slope, residual, y, pad_out, s_lo, s_hi);
   PCONV_LAUNCH_CHECK("ee_conv_bulk_mfma");
   return PCONV_OK;
 }

@@ -92,15 +92,19 @@ class EntropyEngine(object):
     def encode(self, symbols):
         """symbols (nimg*npart, ngroup, h, w) float indices, dead columns zero -> [bytes] per frame"""
         self._check_symbols(symbols)
+        call("pconv_ee_set_encode_ranges", self.handle, 0)  # (the default: a lone call's coding is all tail)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             call("pconv_ee_encode", self.handle, symbols.data_ptr(), stream)
         return self._streams()
 
-    def encode_begin(self, symbols):
+    def encode_begin(self, symbols, ranges=0):
         """first half of encode: queues the GPU part and starts the host coder thread, returns at
-        once; the caller may queue other GPU work before encode_end()"""
+        once; the caller may queue other GPU work before encode_end().  ranges: step ranges the call's
+        last group is evaluated in (0 = the engine's default, 1 = one piece: for calls whose coding
+        hides under later GPU work)"""
         self._check_symbols(symbols)
+        call("pconv_ee_set_encode_ranges", self.handle, int(ranges))
         self._pending = symbols  # kept alive until encode_end
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -277,7 +281,8 @@ class CodecEngine(object):
                 else:
                     sym = self.symbols(frames[lo:lo + chunk]).contiguous()
                 eng = self._engine("enc", sym.shape[2], sym.shape[3], sym.shape[0] // tiles, slot=k)
-                eng.encode_begin(sym)
+                # only the last chunk's arithmetic coding is a tail nothing hides: only it is worth step ranges
+                eng.encode_begin(sym, ranges=0 if lo + chunk >= n else 1)
                 pending.append(eng)
         except BaseException:
             # a later chunk failed: join the coder threads of the chunks already started, or their

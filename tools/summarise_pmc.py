@@ -45,6 +45,7 @@ def read_pass(d):
 def main():
     args = sys.argv[1:]
     out_path, dirs, flops, trace = args[0], [], {}, None
+    algo_bytes = {}
     i = 1
     while i < len(args):
         if args[i] == "--flops":
@@ -66,6 +67,10 @@ def main():
                 d[1] += r["launches"]
             for k, (fl, n) in per.items():
                 flops[k.replace(", ", ", ")] = fl / n
+            # ... and the algorithmic bytes per launch of the HBM-bound kernels (`hbm` rows of the same line), so
+            # that bench.py can rescale the counted bytes when its launches are of another size than this pass's
+            for r in json.loads(line).get("hbm", []):
+                algo_bytes[r["kernel"]] = r["mb_per_launch"] * 1e6
             i += 2
         else:
             dirs.append(args[i])
@@ -95,6 +100,8 @@ def main():
             rec["mfma_busy"] = round(mfma / (busy / 32.0 * 1024.0), 4)
         if k in flops:
             rec["algorithmic_flops_per_launch"] = flops[k]
+        if k in algo_bytes:
+            rec["algorithmic_bytes_per_launch"] = algo_bytes[k]
         kernels[k] = rec
     doc = {"what": "rocprofv3 --pmc passes, averages per launch, per kernel instantiation",
            "passes": [os.path.basename(os.path.normpath(d)) for d in dirs],
