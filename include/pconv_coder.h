@@ -59,6 +59,16 @@ int pconv_coder_decodes(pconv_coder *c, const int32_t *table, int ncode, float *
 /* same, integer output (used by the native decode loop) */
 int pconv_coder_decodes_i32(pconv_coder *c, const int32_t *table, int ncode, int32_t *out, int n);
 
+
+/* The same two loops over PACKED rows of the codec's shape (8 symbols, total 65536): 16 bytes per symbol instead
+ * of the 36 + 4 of an int32[9] row and its int32 label -- what the native entropy engine moves across PCIe
+ * (csrc/engine.cpp; encodes / decodes of python.cpp:22-61 are called with exactly such rows by
+ * pseudo_codec.py:107,153).  Row i = uint16 rows[8 i .. 8 i + 7]: c1 .. c7 of the CDF (c0 = 0 and c8 = 65536 are
+ * implied), then an auxiliary word: bits 0-7 the symbol to encode (ignored by the decoder), bit 7 + k set when
+ * c_k == 65536 (stored as 0).  Same interval arithmetic, same streams, same error returns as the int32 rows. */
+int pconv_coder_encodes_rows16(pconv_coder *c, const uint16_t *rows, int n);
+int pconv_coder_decodes_rows16_i32(pconv_coder *c, const uint16_t *rows, int32_t *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,8 @@ _CODER_SIGNATURES = {
     "pconv_coder_decode": ([c_void_p, P, c_uint32, c_uint32], c_int),
     "pconv_coder_decodes": ([c_void_p, P, c_int, P, c_int], c_int),
     "pconv_coder_decodes_i32": ([c_void_p, P, c_int, P, c_int], c_int),
+    "pconv_coder_encodes_rows16": ([c_void_p, P, c_int], c_int),
+    "pconv_coder_decodes_rows16_i32": ([c_void_p, P, P, c_int], c_int),
 }
 
 _hip = None

@@ -271,13 +271,46 @@ struct pconv_coder {
 // stores them, and its error paths make the compiler assume they may alias).  Same operations, same order, same
 // checks; rows of another shape end the fast loop (the caller goes on with the general path).  Returns the
 // number of rows done, or < 0.
-template <typename T>
-static int decode_rows_8x65536(pconv_coder *c, const int32_t *table, T *out, int n) {
+// Where the rows of the fast loops come from.  RowsI32: the reference's int32[n][9] tables.  Rows16: the engine's
+// packed rows, 16 bytes per symbol -- uint16 c1 .. c7 (c0 = 0 and c8 = 65536 are implied) and an auxiliary word:
+// bits 0-7 the symbol (encoder), bit 7 + k set when c_k is 65536 and was stored as 0 (a row whose top bins are
+// empty: kept exact, so that the coder reports it exactly as it would for the int32 row).  Less than half the
+// bytes of the int32 rows + labels cross PCIe (16 instead of 40 per symbol).
+struct RowsI32 {
+  const int32_t *table;
+  const int32_t *symbols;
+  inline const uint32_t *row(int i, uint32_t *) const { return reinterpret_cast<const uint32_t *>(table + (size_t)i * 9); }
+  inline uint32_t symbol(int i) const { return (uint32_t)symbols[i]; }
+};
+struct Rows16 {
+  const uint16_t *rows;
+  inline const uint32_t *row(int i, uint32_t *t) const {
+    const uint16_t *r = rows + (size_t)i * 8;
+    const uint32_t aux = r[7];
+    t[0] = 0;
+    // (the widening of the seven entries is one vector instruction; the flag bits are all clear except in rows
+    // whose top bins are empty, or that the GPU marked as not of this shape)
+#pragma GCC unroll 7
+    for (int k = 1; k < 8; k++) t[k] = (uint32_t)r[k - 1];
+    t[8] = 65536u;
+    if (__builtin_expect((aux & 0xff00u) != 0, 0)) {
+#pragma GCC unroll 7
+      for (int k = 1; k < 8; k++) t[k] += ((aux >> (7 + k)) & 1u) << 16;
+      if (aux & 0x8000u) t[8] = 0;  // not a row of this shape: ends the fast loop, the caller reports it
+    }
+    return t;
+  }
+  inline uint32_t symbol(int i) const { return rows[(size_t)i * 8 + 7] & 0xffu; }
+};
+
+template <typename T, typename Rows>
+static int decode_rows_8x65536(pconv_coder *c, const Rows &rows, T *out, int n) {
   uint64_t low = c->low, high = c->high, code = c->code;
   BitSource src = c->source;
   int i = 0, rc = 0;
   for (; i < n; i++) {
-    const uint32_t *t = reinterpret_cast<const uint32_t *>(table + (size_t)i * 9);
+    uint32_t unpacked[9];
+    const uint32_t *t = rows.row(i, unpacked);
     if (t[8] != 65536u) break;
     const uint64_t range = high - low + 1;
     if (low >= high || range < kMinRange || range > kMaxRange) {
@@ -336,7 +369,7 @@ static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, 
   const int stride = ncode + 1;
   int first = 0;
   if (ncode == 8) {
-    first = decode_rows_8x65536(c, table, out, n);
+    first = decode_rows_8x65536(c, RowsI32{table, nullptr}, out, n);
     if (first < 0) return first;
   }
   for (int i = first; i < n; i++) {
@@ -347,6 +380,69 @@ static int decode_many(pconv_coder *c, const int32_t *table, int ncode, T *out, 
     out[i] = (T)s;
   }
   return 0;
+}
+
+// The codec's rows (8 symbols, total 65536) in a row: returns the number of rows coded (rows of another shape end
+// the loop: the caller goes on with the general path), or < 0.
+template <typename Rows>
+static int encode_rows_8x65536(pconv_coder *c, const Rows &rows, int n) {
+  int i = 0;
+  {
+    // the codec's rows (8 symbols, total 65536): narrow<true>() with the interval in registers and the two
+    // divisions by the total as shifts; rows of another shape end the fast loop
+    uint64_t low = c->low, high = c->high, pending = c->pending;
+    // <= 33 bits leave the state per symbol, deferred bits of THIS call included; the bits deferred by earlier
+    // calls (`pending` at entry) are flushed through the checked put_run() but land in the same buffer
+    c->sink.reserve((size_t)n * 5 + 64 + (size_t)(pending / 8) + 8);
+    int rc = 0;
+    for (; i < n; i++) {
+      uint32_t unpacked[9];
+      const uint32_t *row = rows.row(i, unpacked);
+      if (row[8] != 65536u) break;
+      const uint32_t s = rows.symbol(i);
+      if (s >= 8u) {
+        rc = c->fail(PCONV_CODER_EARG, "symbol out of range");
+        break;
+      }
+      const uint64_t range = high - low + 1;
+      if (low >= high || range < kMinRange || range > kMaxRange) {
+        rc = c->fail(PCONV_CODER_ESTATE, "Assertion error: Range out of range");
+        break;
+      }
+      const uint32_t sym_low = row[s], sym_high = row[s + 1];
+      if (sym_low == sym_high) {
+        rc = c->fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
+        break;
+      }
+      high = low + ((sym_high * range) >> 16) - 1;
+      low = low + ((sym_low * range) >> 16);
+      const int agree = clz32((uint32_t)((low ^ high) & kMask));
+      if (agree > 0) {
+        const uint32_t top = (uint32_t)(low >> (kStateBits - agree));
+        if (__builtin_expect(pending == 0, 1)) {
+          c->sink.put_reserved(top, agree);  // (the first bit and the rest in one piece)
+        } else {
+          const int firstbit = (top >> (agree - 1)) & 1;
+          c->sink.put(firstbit, 1);
+          c->sink.put_run(firstbit ^ 1, pending);
+          pending = 0;
+          if (agree > 1) c->sink.put(top & ((1u << (agree - 1)) - 1), agree - 1);
+        }
+        low = (low << agree) & kMask;
+        high = ((high << agree) & kMask) | ((1ull << agree) - 1);
+      }
+      const uint32_t pattern = (uint32_t)((low & ~high & (kMask >> 1)) << 1);
+      const int squeeze = clz32(~pattern);
+      if (squeeze > 0) {
+        pending += squeeze;
+        low = (low << squeeze) & (kMask >> 1);
+        high = ((high << squeeze) & (kMask >> 1)) | kTop | ((1ull << squeeze) - 1);
+      }
+    }
+    c->low = low, c->high = high, c->pending = pending;
+    if (rc < 0) return rc;
+  }
+  return i;
 }
 
 extern "C" {
@@ -397,58 +493,8 @@ int pconv_coder_encodes(pconv_coder *c, const int32_t *table, int ncode, const i
   const int stride = ncode + 1;
   int i = 0;
   if (ncode == 8) {
-    // the codec's rows (8 symbols, total 65536): narrow<true>() with the interval in registers and the two
-    // divisions by the total as shifts; rows of another shape end the fast loop
-    uint64_t low = c->low, high = c->high, pending = c->pending;
-    // <= 33 bits leave the state per symbol, deferred bits of THIS call included; the bits deferred by earlier
-    // calls (`pending` at entry) are flushed through the checked put_run() but land in the same buffer
-    c->sink.reserve((size_t)n * 5 + 64 + (size_t)(pending / 8) + 8);
-    int rc = 0;
-    for (; i < n; i++) {
-      const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * 9);
-      if (row[8] != 65536u) break;
-      const uint32_t s = (uint32_t)symbols[i];
-      if (s >= 8u) {
-        rc = c->fail(PCONV_CODER_EARG, "symbol out of range");
-        break;
-      }
-      const uint64_t range = high - low + 1;
-      if (low >= high || range < kMinRange || range > kMaxRange) {
-        rc = c->fail(PCONV_CODER_ESTATE, "Assertion error: Range out of range");
-        break;
-      }
-      const uint32_t sym_low = row[s], sym_high = row[s + 1];
-      if (sym_low == sym_high) {
-        rc = c->fail(PCONV_CODER_EZEROFREQ, "Symbol has zero frequency");
-        break;
-      }
-      high = low + ((sym_high * range) >> 16) - 1;
-      low = low + ((sym_low * range) >> 16);
-      const int agree = clz32((uint32_t)((low ^ high) & kMask));
-      if (agree > 0) {
-        const uint32_t top = (uint32_t)(low >> (kStateBits - agree));
-        if (__builtin_expect(pending == 0, 1)) {
-          c->sink.put_reserved(top, agree);  // (the first bit and the rest in one piece)
-        } else {
-          const int firstbit = (top >> (agree - 1)) & 1;
-          c->sink.put(firstbit, 1);
-          c->sink.put_run(firstbit ^ 1, pending);
-          pending = 0;
-          if (agree > 1) c->sink.put(top & ((1u << (agree - 1)) - 1), agree - 1);
-        }
-        low = (low << agree) & kMask;
-        high = ((high << agree) & kMask) | ((1ull << agree) - 1);
-      }
-      const uint32_t pattern = (uint32_t)((low & ~high & (kMask >> 1)) << 1);
-      const int squeeze = clz32(~pattern);
-      if (squeeze > 0) {
-        pending += squeeze;
-        low = (low << squeeze) & (kMask >> 1);
-        high = ((high << squeeze) & (kMask >> 1)) | kTop | ((1ull << squeeze) - 1);
-      }
-    }
-    c->low = low, c->high = high, c->pending = pending;
-    if (rc < 0) return rc;
+    i = encode_rows_8x65536(c, RowsI32{table, symbols}, n);
+    if (i < 0) return i;
   }
   for (; i < n; i++) {
     const uint32_t *row = reinterpret_cast<const uint32_t *>(table + (size_t)i * stride);
@@ -524,6 +570,26 @@ int pconv_coder_decodes(pconv_coder *c, const int32_t *table, int ncode, float *
 
 int pconv_coder_decodes_i32(pconv_coder *c, const int32_t *table, int ncode, int32_t *out, int n) {
   return decode_many<int32_t>(c, table, ncode, out, n);
+}
+
+int pconv_coder_encodes_rows16(pconv_coder *c, const uint16_t *rows, int n) {
+  if (!c) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::ENCODING) return c->fail(PCONV_CODER_ESTATE, "encoder not started");
+  if (n <= 0) return 0;
+  if (!rows) return c->fail(PCONV_CODER_EARG, "null rows");
+  const int done = encode_rows_8x65536(c, Rows16{rows}, n);
+  if (done < 0) return done;
+  return done == n ? 0 : c->fail(PCONV_CODER_EARG, "packed rows are 8 symbols of total 65536");
+}
+
+int pconv_coder_decodes_rows16_i32(pconv_coder *c, const uint16_t *rows, int32_t *out, int n) {
+  if (!c) return PCONV_CODER_EARG;
+  if (c->mode != pconv_coder::DECODING) return c->fail(PCONV_CODER_ESTATE, "decoder not started");
+  if (n <= 0) return 0;
+  if (!rows || !out) return c->fail(PCONV_CODER_EARG, "null rows or output");
+  const int done = decode_rows_8x65536(c, Rows16{rows}, out, n);
+  if (done < 0) return done;
+  return done == n ? 0 : c->fail(PCONV_CODER_EARG, "packed rows are 8 symbols of total 65536");
 }
 
 }  // extern "C"

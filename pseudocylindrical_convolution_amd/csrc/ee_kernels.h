@@ -94,9 +94,11 @@ int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n
                       const float *residual, float *y, int cin, int cout, int pad_out, int s_lo, int s_hi,
                       void *stream);
 // CDF rows and labels of the symbols of those steps, written in stream order
+// packed != 0 (8 symbols, total 65536 only): `table` receives the coder's 16-byte rows (uint16 c1 .. c7 + label, see
+// include/pconv_coder.h pconv_coder_encodes_rows16), `labels` is not written
 int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
                    int nstep, float bias, float total, float beta, int first_idx, int n_idx, int s_lo, int s_hi,
-                   void *stream);
+                   int packed, void *stream);
 
 // halos and wrap columns of a whole buffer of `nrep` images with C channels from
 // its interior (bulk mode, after a layer has been evaluated everywhere)
@@ -115,6 +117,7 @@ int ee_read_symbols(const EeGeom *g, const float *ctx, float *symbols, float bia
 // integer CDF rows of one step from the last layer's output (unpadded, 3*ngroup
 // channels); optional labels from the NCHW symbol tensor.  flags != null: once all rows are
 // written the kernel stores flags[1] = publish (system scope); counter: a zeroed device int.
+// packed != 0 (decoder form only: nstep 8, no symbols): 16-byte rows as above, one store per row
 int ee_tables(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
               int lo, int len, int psum, int nstep, float bias, float total, float beta, int32_t *counter,
-              int32_t *flags, int publish, void *stream);
+              int32_t *flags, int publish, int packed, void *stream);

@@ -282,6 +282,9 @@ struct Group {
   hipEvent_t enc_done[8] = {nullptr};  // ... and "this range's rows are on the host"
   float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
   float *act[kLayers] = {nullptr};  // (3*nimg*npart, h+2p, w+2p, 3G), persistent across steps
+  // CDF rows of the group's symbols.  Packed engine (8 symbols, total 65536: the codec): 16-byte rows (uint16 c1 .. c7
+  // + label, include/pconv_coder.h) in tables_d / tables_h, no label arrays; otherwise int32 rows of nlevels + 1
+  // entries and int32 labels
   int32_t *tables_d = nullptr, *labels_d = nullptr;
   int32_t *tables_h = nullptr, *labels_h = nullptr;  // pinned
   float *packed_h = nullptr;                         // pinned; decoder: symbols of the previous step [img][len]
@@ -334,6 +337,11 @@ struct pconv_entropy_engine {
   std::chrono::steady_clock::time_point enc_begin;
   double enc_wait = 0, enc_coder = 0;
 
+  // 16-byte packed rows across PCIe instead of int32 rows + labels (40 bytes per symbol) when the tables have the
+  // codec's shape; PCONV_ENGINE_ROWS=int32 keeps the wide rows (A/B); the step-by-step debugging encoder needs them
+  bool packed = false;
+  size_t row_bytes() const { return packed ? 16 : (size_t)(nlevels + 1) * 4; }
+
   size_t ctx_elems(int n) const { return (size_t)n * npart * ngroup * (h + 2 * kPad) * (w + 2 * kPad); }
   size_t act_elems(int l, int n) const {
     const int p = (l == kLayers - 1) ? 0 : kPad;
@@ -369,10 +377,12 @@ struct pconv_entropy_engine {
     HIP_TRY(hipMalloc(&g.ctx, ctx_elems(n) * 4));
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&g.act[l], act_elems(l, n) * 4));
     const size_t all_rows = sym_per_img * n;
-    HIP_TRY(hipMalloc(&g.tables_d, all_rows * (nlevels + 1) * 4));
-    HIP_TRY(hipMalloc(&g.labels_d, all_rows * 4));
-    HIP_TRY(hipHostMalloc(&g.tables_h, all_rows * (nlevels + 1) * 4));
-    HIP_TRY(hipHostMalloc(&g.labels_h, all_rows * 4));
+    HIP_TRY(hipMalloc(&g.tables_d, all_rows * row_bytes()));
+    HIP_TRY(hipHostMalloc(&g.tables_h, all_rows * row_bytes()));
+    if (!packed) {
+      HIP_TRY(hipMalloc(&g.labels_d, all_rows * 4));
+      HIP_TRY(hipHostMalloc(&g.labels_h, all_rows * 4));
+    }
     HIP_TRY(hipHostMalloc(&g.packed_h, (size_t)n * max_len * 4));
     HIP_TRY(hipHostMalloc(&g.flags_h, 64, hipHostMallocCoherent | hipHostMallocMapped));
     HIP_TRY(hipMalloc(&g.counter_d, 64));
@@ -383,6 +393,11 @@ struct pconv_entropy_engine {
   int init(const float *tile_weight) {
     rows = h * npart;
     nsteps = rows + w + ngroup - 2;
+    stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
+    {
+      const char *env = getenv("PCONV_ENGINE_ROWS");
+      packed = nlevels == 8 && total == 65536.f && !stepwise_encoder && !(env && env[0] == 'i');
+    }
     widths.assign(npart, 0);
     PC_TRY(pconv_host_tile_widths(tile_weight, npart, rows, w, widths.data()));
     std::vector<int32_t> order((size_t)rows * w);
@@ -502,7 +517,6 @@ struct pconv_entropy_engine {
       HIP_TRY(hipMemcpy(pos_plane_d, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
       base.pos_plane = pos_plane_d;
       base.npos = npos;
-      stepwise_encoder = getenv("PCONV_ENGINE_STEPWISE_ENCODER") != nullptr;
     }
     for (int l = 0; l < kLayers; l++) HIP_TRY(hipMalloc(&lw[l], ee_packed_floats(3, 3 * ngroup, layer_cin(l)) * 4));
     {
@@ -709,7 +723,7 @@ struct pconv_entropy_engine {
         const Window cur = window(s);
         PC_TRY(network_step(g, s, cur));
         PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], sym, g.tables_d + (size_t)g.step_row[s] * cols,
-                         g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, nullptr, nullptr, 0,
+                         g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, nullptr, nullptr, 0, 0,
                          g.stream));
       }
     } else {
@@ -724,12 +738,14 @@ struct pconv_entropy_engine {
         step_range_entries(s_lo, s_hi, &first, &count);
         PC_TRY(network_bulk(g, s_lo, s_hi));
         PC_TRY(ee_tables_bulk(&g.geom, g.act[kLayers - 1], sym, g.tables_d, g.labels_d, nlevels, bias, total, beta, first,
-                              count, s_lo, s_hi, g.stream));
+                              count, s_lo, s_hi, packed, g.stream));
         const size_t r0 = g.step_row[s_lo], r1 = g.step_row[s_hi];
         if (r1 > r0) {
-          HIP_TRY(hipMemcpyAsync(g.tables_h + r0 * cols, g.tables_d + r0 * cols, (r1 - r0) * cols * 4, hipMemcpyDeviceToHost,
-                                 g.stream));
-          HIP_TRY(hipMemcpyAsync(g.labels_h + r0, g.labels_d + r0, (r1 - r0) * 4, hipMemcpyDeviceToHost, g.stream));
+          const size_t rb = row_bytes();
+          HIP_TRY(hipMemcpyAsync((char *)g.tables_h + r0 * rb, (const char *)g.tables_d + r0 * rb, (r1 - r0) * rb,
+                                 hipMemcpyDeviceToHost, g.stream));
+          if (!packed)
+            HIP_TRY(hipMemcpyAsync(g.labels_h + r0, g.labels_d + r0, (r1 - r0) * 4, hipMemcpyDeviceToHost, g.stream));
         }
         HIP_TRY(hipEventRecord(g.enc_done[k], g.stream));
       }
@@ -768,7 +784,7 @@ struct pconv_entropy_engine {
     if (cur.len > 0) {
       PC_TRY(network_step(g, s, cur));
       PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_h, nullptr, cur.lo, cur.len, s, nlevels, bias,
-                       total, beta, g.counter_d, flags, s + 1, g.stream));
+                       total, beta, g.counter_d, flags, s + 1, packed, g.stream));
     }
     return PCONV_OK;
   }
@@ -780,8 +796,11 @@ struct pconv_entropy_engine {
     g.sym.resize(nrow);
     std::atomic<int> status{0};
     const std::function<void(int)> job = [&](int i) {
-      const int rc = pconv_coder_decodes_i32(coders[g.first + i], g.tables_h + (size_t)i * cur.len * cols, nlevels,
-                                             g.sym.data() + (size_t)i * cur.len, cur.len);
+      const int rc =
+          packed ? pconv_coder_decodes_rows16_i32(coders[g.first + i], (const uint16_t *)g.tables_h + (size_t)i * cur.len * 8,
+                                                  g.sym.data() + (size_t)i * cur.len, cur.len)
+                 : pconv_coder_decodes_i32(coders[g.first + i], g.tables_h + (size_t)i * cur.len * cols, nlevels,
+                                           g.sym.data() + (size_t)i * cur.len, cur.len);
       if (rc < 0) status.store(rc);
       float *dst = g.packed_h + (size_t)i * cur.len;
       const int32_t *src = g.sym.data() + (size_t)i * cur.len;
@@ -1001,7 +1020,8 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
           const size_t len = (size_t)(g.step_row[s + 1] - g.step_row[s]) / g.nimg;
           if (!len) continue;
           const size_t r0 = (size_t)g.step_row[s] + (size_t)i * len;
-          rc = pconv_coder_encodes(c, g.tables_h + r0 * cols, e->nlevels, g.labels_h + r0, (int)len);
+          rc = e->packed ? pconv_coder_encodes_rows16(c, (const uint16_t *)g.tables_h + r0 * 8, (int)len)
+                         : pconv_coder_encodes(c, g.tables_h + r0 * cols, e->nlevels, g.labels_h + r0, (int)len);
         }
         if (rc >= 0) rc = pconv_coder_end_encoder(c);
         if (rc < 0) {

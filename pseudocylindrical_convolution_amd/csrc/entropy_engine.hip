@@ -30,6 +30,25 @@ constexpr int K = 5, KK = 25, HALF = 2, PAD = 2, GO = 3;
 struct Pos {
   int tw, row, tg, th;
 };
+
+// An integer CDF row of the codec's shape (8 symbols, total 65536) as the coder's packed 16-byte row
+// (include/pconv_coder.h): uint16 c1 .. c7, then an auxiliary word -- bits 0-7 the label, bit 7 + k: c_k == 65536
+// (stored as 0), bit 15: the row does not have this shape (the coder then refuses it, as it refuses an int32 row
+// whose total is off).  16 bytes per symbol cross PCIe instead of 36 + 4.
+__device__ __forceinline__ uint4 pack_row16(const int32_t *row, unsigned label) {
+  unsigned aux = label & 0xffu;
+  unsigned hw[7];
+  bool ok = row[0] == 0 && row[8] == 65536;
+#pragma unroll
+  for (int k = 1; k < 8; k++) {
+    const unsigned v = (unsigned)row[k];
+    ok = ok && v <= 65536u;
+    hw[k - 1] = v & 0xffffu;
+    aux |= (v == 65536u ? 1u : 0u) << (7 + k);
+  }
+  if (!ok) aux |= 0x8000u;
+  return make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (aux << 16));
+}
 __device__ __forceinline__ Pos decode_pos(int hw, int h, int w) {
   Pos p;
   p.tw = hw % w;
@@ -799,7 +818,7 @@ __global__ void ee_tables_kernel(EeGeom g, const float *__restrict__ y, const fl
 // in a launch of a few hundred waves: pure latency, 3x longer than a layer of the network.
 __global__ void ee_tables8_kernel(EeGeom g, const float *__restrict__ y, int32_t *__restrict__ table, int lo,
                                   int len, int psum, float bias, float total, float beta, int32_t *counter,
-                                  volatile int32_t *flags, int publish) {
+                                  volatile int32_t *flags, int publish, int packed) {
   constexpr int NS = 8;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = tid >> 3, q = tid & 7;
@@ -844,9 +863,21 @@ __global__ void ee_tables8_kernel(EeGeom g, const float *__restrict__ y, int32_t
       prev = c;
     }
     if (shift > 0 && q >= widest_at) mine = (float)(int32_t)mine - shift;
-    int32_t *row = table + ((size_t)n * len + l) * (NS + 1);
-    row[q + 1] = (int32_t)mine;
-    if (q == 0) row[0] = 0;
+    if (!packed) {
+      int32_t *row = table + ((size_t)n * len + l) * (NS + 1);
+      row[q + 1] = (int32_t)mine;
+      if (q == 0) row[0] = 0;
+    }
+    cur = mine;
+  }
+  if (packed) {
+    // the octet's eight entries meet in every lane; its first lane stores the row as ONE 16-byte piece (the rows go
+    // straight to pinned host memory: one PCIe write per row instead of nine 4-byte ones)
+    int32_t row[NS + 1];
+    row[0] = 0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) row[i + 1] = (int32_t)__shfl(cur, base_lane + i, 64);
+    if (live && q == 0) reinterpret_cast<uint4 *>(table)[(size_t)n * len + l] = pack_row16(row, 0u);
   }
   if (flags) {
     __syncthreads();  // every wave of the block has drained its stores (vmcnt(0) before the barrier)
@@ -866,7 +897,7 @@ __global__ void ee_tables8_kernel(EeGeom g, const float *__restrict__ y, int32_t
 __global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, const float *__restrict__ symbols,
                                       int32_t *__restrict__ table, int32_t *__restrict__ labels, int nstep,
                                       float bias, float total, float beta, long long count, int first_idx, int n_idx,
-                                      int s_lo, int s_hi) {
+                                      int s_lo, int s_hi, int packed) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (long long)gridDim.x * blockDim.x) {
     const int idx = first_idx + (int)(i % n_idx);
@@ -891,8 +922,15 @@ __global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, con
       for (int k = 0; k < 3; k++) par[rep][k] = base[k];
     }
     gmm_prepare_row(par[0], par[1], 3, beta);
-    gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
-    labels[r] = (int32_t)symbols[((((size_t)n * g.npart + p.tg) * g.ngroup + tc) * g.h + p.th) * g.w + p.tw];
+    const int32_t label = (int32_t)symbols[((((size_t)n * g.npart + p.tg) * g.ngroup + tc) * g.h + p.th) * g.w + p.tw];
+    if (packed) {  // (nstep == 8: checked on the host)
+      int32_t row[9];
+      gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, 8, bias, total, 1, row);
+      reinterpret_cast<uint4 *>(table)[r] = pack_row16(row, (unsigned)label);
+    } else {
+      gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
+      labels[r] = label;
+    }
   }
 }
 
@@ -900,12 +938,13 @@ __global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, con
 
 int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels,
                    int nstep, float bias, float total, float beta, int first_idx, int n_idx, int s_lo, int s_hi,
-                   void *stream) {
+                   int packed, void *stream) {
   PCONV_REQUIRE(first_idx >= 0 && n_idx >= 0 && first_idx + n_idx <= g->npos && s_lo < s_hi, "ee_tables_bulk: bad range");
+  PCONV_REQUIRE(!packed || (nstep == 8 && total == 65536.f), "ee_tables_bulk: packed rows are 8 symbols of total 65536");
   if (n_idx == 0) return PCONV_OK;
   const long long count = (long long)g->nimg * g->ngroup * n_idx;
   hipLaunchKernelGGL(ee_tables_bulk_kernel, dim3(pconv_grid(count)), dim3(256), 0, as_stream(stream), *g, y_last,
-                     symbols, table, labels, nstep, bias, total, beta, count, first_idx, n_idx, s_lo, s_hi);
+                     symbols, table, labels, nstep, bias, total, beta, count, first_idx, n_idx, s_lo, s_hi, packed);
   PCONV_LAUNCH_CHECK("ee_tables_bulk");
   return PCONV_OK;
 }
@@ -1064,11 +1103,12 @@ int ee_read_symbols(const EeGeom *g, const float *ctx, float *symbols, float bia
 
 int ee_tables(const EeGeom *g, const float *y_last, const float *symbols, int32_t *table, int32_t *labels, int lo,
               int len, int psum, int nstep, float bias, float total, float beta, int32_t *counter, int32_t *flags,
-              int publish, void *stream) {
+              int publish, int packed, void *stream) {
   if (len <= 0) return PCONV_OK;
+  PCONV_REQUIRE(!packed || (nstep == 8 && !symbols && total == 65536.f), "ee_tables: packed rows are the decoder's 8 x 65536 rows");
   if (nstep == 8 && !symbols) {  // the decoder's form: 8 lanes per row
     hipLaunchKernelGGL(ee_tables8_kernel, dim3((len * 8 + 255) / 256, g->nimg), dim3(256), 0, as_stream(stream), *g,
-                       y_last, table, lo, len, psum, bias, total, beta, counter, (volatile int32_t *)flags, publish);
+                       y_last, table, lo, len, psum, bias, total, beta, counter, (volatile int32_t *)flags, publish, packed);
     PCONV_LAUNCH_CHECK("ee_tables");
     return PCONV_OK;
   }

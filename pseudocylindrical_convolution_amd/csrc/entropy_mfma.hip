@@ -87,7 +87,11 @@ __global__ void pack_weight_mfma_kernel(const float *__restrict__ w, float *__re
 
 // kNT: position tiles of a wave = stacked rows x 16 columns.  2: every weight fragment feeds two MFMAs, 250
 // registers, two waves per SIMD; 1: 15 MFMAs per class and wave, <= 168 registers, three waves per SIMD
-template <int CIN, int WAVES, int kNT>
+// DIRECT (with kNT == 1): no LDS ring and no barrier in the class loop -- every wave fetches the next class's
+// fragments itself, straight from global memory into registers (4 KB per wave and class, the four waves of a
+// workgroup and its neighbours on the CU read the same lines within a few classes of each other: L1 / L2 hits),
+// under the current class's matrix instructions.
+template <int CIN, int WAVES, int kNT, bool DIRECT>
 __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_mfma_kernel(
     EeGeom g, const int4 *__restrict__ blocks, int rp_n, int ct_n, const float *__restrict__ x, int shared_input,
     const float *__restrict__ wfrag, const float *__restrict__ bias, const float *__restrict__ slope,
@@ -98,8 +102,9 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   static_assert(COUT <= 16 * kMT, "three output tiles");
   static_assert(QUADS <= 4, "a class's fragments are four 16-byte pieces per lane at most");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *ring = smem;                 // kRing x FRAG floats
-  float *patch = smem + kRing * FRAG; // (BR + 4) x (BC + 4) x CIN
+  static_assert(!DIRECT || kNT == 1, "direct weight fetch goes with the pipelined one-row form");
+  float *ring = smem;                                  // kRing x FRAG floats (none with DIRECT)
+  float *patch = smem + (DIRECT ? 0 : kRing * FRAG);   // (BR + 4) x (BC + 4) x CIN
   typedef const __attribute__((address_space(4))) int32_t const_i32_t;
   const_i32_t *brec = (const_i32_t *)(blocks + blockIdx.x);
   const int tile = brec[0], row0 = brec[1], col0 = brec[2];
@@ -133,9 +138,12 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   // PIPE (one row per wave: registers to spare): the operands of class i + 1 are read from LDS while the matrix
   // instructions of class i run, so the weight ring runs one class further ahead
   constexpr bool PIPE = kNT == 1;
-  store_class(0, fetch_class(0));
-  if (PIPE) store_class(1, fetch_class(1));
-  piece_t wnext = fetch_class(PIPE ? 2 : 1);
+  piece_t wnext = fetch_class(0);
+  if (!DIRECT) {
+    store_class(0, wnext);
+    if (PIPE) store_class(1, fetch_class(1));
+    wnext = fetch_class(PIPE ? 2 : 1);
+  }
   {
     // the patch: PR rows of PW * CIN contiguous floats each (a pixel is 168 bytes), by LDS-DMA in 16-byte pieces
     // (8-byte aligned sources: tools/dma16_probe.hip), every piece of the workgroup in flight at once -- a loop of
@@ -192,8 +200,9 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   for (int t = 0; t < kMT * kNT; t++) S1[t] = S2[t] = S3[t] = P3[t] = P4[t] = P5[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // operands of a class: A fragments (slot s = 3 m + mt of the ring slot) and this lane's B entries of the patch
+  // (slot: ring slot of the class; with DIRECT: the class order index, fragments straight from global memory)
   auto read_operands = [&](int slot, int l, float (&af)[QUADS * 4], float (&bf)[STEPS][kNT]) {
-    const float4 *fr = reinterpret_cast<const float4 *>(ring + slot * FRAG) + lane;
+    const float4 *fr = reinterpret_cast<const float4 *>(DIRECT ? wset + (size_t)slot * FRAG : ring + slot * FRAG) + lane;
 #pragma unroll
     for (int qd = 0; qd < QUADS; qd++) {
       const float4 v = fr[qd * kWave];
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   float af[QUADS * 4], bf[STEPS][kNT];
   if (PIPE) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the patch DMA, classes 0 and 1
+    if (DIRECT && !live) return;  // (no barrier from here on)
     if (live) read_operands(0, 0, af, bf);
   }
 #pragma unroll 1
@@ -221,15 +231,17 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
       const int i = a * 8 + b;
       float afn[QUADS * 4], bfn[STEPS][kNT];
       if (PIPE) {
-        // class i + 1 is in its slot (stored during step i - 1); the barrier waits for the LDS stores only --
-        // __syncthreads() would also wait for the weight load in flight
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        store_class(i + 2, wnext);  // (slot (i + 2) & 3 was last read in step i - 3; past the end: a dummy)
-        wnext = fetch_class(i + 3 < 64 ? i + 3 : 63);
-        if (!live) continue;  // (wave-uniform; the barriers stay outside)
+        if (!DIRECT) {
+          // class i + 1 is in its slot (stored during step i - 1); the barrier waits for the LDS stores only --
+          // __syncthreads() would also wait for the weight load in flight
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          store_class(i + 2, wnext);  // (slot (i + 2) & 3 was last read in step i - 3; past the end: a dummy)
+          wnext = fetch_class(i + 3 < 64 ? i + 3 : 63);
+          if (!live) continue;  // (wave-uniform; the barriers stay outside)
+        }
         // the next class's operands, in flight under this class's matrix instructions
         const int ln = b < 7 ? bitrev3(b + 1) * 8 + la : bitrev3((a + 1) & 7);
-        read_operands((b + 1) & (kRing - 1), ln, afn, bfn);  // (behind the last class: a dummy)
+        read_operands(DIRECT ? (i + 1 < 64 ? i + 1 : 63) : (b + 1) & (kRing - 1), ln, afn, bfn);  // (behind the last class: a dummy)
       } else {
         // class i is in its slot (stored during step i - 1; at i = 0: with the patch)
         if (a == 0 && b == 0)
@@ -338,6 +350,12 @@ int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int c
 
 // a block is nt * rp_n rows x 16 ct_n columns, rp_n * ct_n = waves of a workgroup, nt = rows of a wave (1 or 2;
 // PCONV_EE_MFMA_NT); rows per tile must be a multiple of nt * rp_n
+// PCONV_EE_MFMA_WSRC=ring: the LDS-ring form of the one-row kernel (default: direct fetch)
+static bool mfma_direct(int nt) {
+  static const bool ring = getenv("PCONV_EE_MFMA_WSRC") && getenv("PCONV_EE_MFMA_WSRC")[0] == 'r';
+  return nt == 1 && !ring;
+}
+
 int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves, int *nt) {
   static const int wv = getenv("PCONV_EE_MFMA_WAVES") ? atoi(getenv("PCONV_EE_MFMA_WAVES")) : 4;
   // measured (MI355X, 4096x2048, one frame x 3 sets per launch, profiles/round5_entropy_mfma_variants.txt): one row per
@@ -370,18 +388,20 @@ int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n
   // ring + patch, the patch rounded up to whole DMA rounds of the workgroup (16 bytes per thread)
   const size_t round = (size_t)waves * kWave * 16;
   const size_t patch_bytes = ((size_t)(nt * rp_n + 4) * (16 * ct_n + 4) * 42 * sizeof(float) + round - 1) / round * round;
-  const size_t smem = (size_t)kRing * frag_floats(42) * sizeof(float) + patch_bytes + kPatchSlack * sizeof(float);
+  const bool direct = mfma_direct(nt);
+  const size_t smem = (direct ? 0 : (size_t)kRing * frag_floats(42) * sizeof(float)) + patch_bytes + kPatchSlack * sizeof(float);
   PCONV_REQUIRE(smem <= 160 * 1024, "ee_conv_bulk_mfma: block needs %zu bytes of LDS", smem);
   const dim3 grid((unsigned)nblocks, (unsigned)(3 * g->nimg));
   PCONV_REQUIRE(grid.y <= 65535u, "ee_conv_bulk_mfma: too many images for one launch");
   typedef void (*kernel_t)(EeGeom, const int4 *, int, int, const float *, int, const float *, const float *, const float *,
                            const float *, float *, int, int, int);
-  const int kind = (waves == 8 ? 2 : 0) + (nt == 1 ? 1 : 0);
-  static const kernel_t kernels[4] = {ee_conv_bulk_mfma_kernel<42, 4, 2>, ee_conv_bulk_mfma_kernel<42, 4, 1>,
-                                      ee_conv_bulk_mfma_kernel<42, 8, 2>, ee_conv_bulk_mfma_kernel<42, 8, 1>};
+  const int kind = direct ? 4 + (waves == 8) : (waves == 8 ? 2 : 0) + (nt == 1 ? 1 : 0);
+  static const kernel_t kernels[6] = {ee_conv_bulk_mfma_kernel<42, 4, 2, false>, ee_conv_bulk_mfma_kernel<42, 4, 1, false>,
+                                      ee_conv_bulk_mfma_kernel<42, 8, 2, false>, ee_conv_bulk_mfma_kernel<42, 8, 1, false>,
+                                      ee_conv_bulk_mfma_kernel<42, 4, 1, true>,  ee_conv_bulk_mfma_kernel<42, 8, 1, true>};
   {
     // the dynamic-LDS limit is a per-device attribute of the function (conv.hip)
-    static std::atomic<unsigned long long> raised[4];
+    static std::atomic<unsigned long long> raised[6];
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) device = 0;
     const unsigned long long bit = 1ULL << (device & 63);

@@ -162,8 +162,8 @@ class CodecEngine(object):
     # activations are GBs at 4096x2048), the rest -- 1/4 scale and below -- on all frames of the call at
     # once; likewise the first SYNTHESIS_SPLIT blocks of DecoderV2.net.  A tile's outputs do not depend
     # on how many tiles a launch carries (same kernel, same per-tile arithmetic): bit-identical either
-    # way (tests/test_codec_cpu.py on the oracle, tests/test_gpu_bench_workload.py on the GPU at the
-    # metric size).  0 = whole transform frame by frame.  Measured (8 frames,
+    # way (tests/test_codec_cpu.py on the oracle; on the GPU at the metric size:
+    # tests/test_gpu_codec_vs_oracle.py::test_benchmarked_workload_eight_frames_at_the_metric_size).  0 = whole transform frame by frame.  Measured (8 frames,
     # profiles/round3_split_transforms.txt): 0/0 52.6, 6/5 54.0, 3/8 54.5 MPix/s.
     ANALYSIS_SPLIT = int(os.environ.get("PCONV_ANALYSIS_SPLIT", "3"))
     SYNTHESIS_SPLIT = int(os.environ.get("PCONV_SYNTHESIS_SPLIT", "8"))

@@ -185,3 +185,81 @@ def test_decoder_reports_zero_frequency_and_survives_garbage(tmp_path):
     got = _decode(product.coder, str(tmp_path / "n.bin"), tab, 300)
     assert (got == _decode(coder_cpu.PyCoder, str(tmp_path / "n.bin"), tab, 300)).all()
     assert _encode(product.coder, str(tmp_path / "b.bin"), tab, got)[:8] == noise[:8]
+
+
+def _pack_rows16(tab, sym=None):
+    """int32[n, 9] CDF rows (+ symbols) -> the engine's packed rows uint16[n, 8] (include/pconv_coder.h)"""
+    tab = np.asarray(tab, dtype=np.int64)
+    rows = np.zeros((len(tab), 8), dtype=np.uint16)
+    rows[:, :7] = (tab[:, 1:8] & 0xffff).astype(np.uint16)
+    aux = np.zeros(len(tab), dtype=np.uint32)
+    for k in range(1, 8):
+        aux |= (tab[:, k] == 65536).astype(np.uint32) << (7 + k)
+    if sym is not None:
+        aux |= np.asarray(sym, dtype=np.uint32) & 0xff
+    rows[:, 7] = aux.astype(np.uint16)
+    return np.ascontiguousarray(rows)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[os.path.basename(c)[6:-4] for c in CASES])
+def test_packed_rows_write_and_read_the_reference_golden_stream(case):
+    """pconv_coder_encodes_rows16 / _decodes_rows16_i32 (16 bytes per symbol across PCIe instead of 40) against the
+    streams of the REFERENCE coder: same bytes, same symbols"""
+    from pseudocylindrical_convolution_amd import _native
+    lib = _native.coder_lib()
+    d = np.load(case)
+    tab, sym, gold = d["tables"], d["symbols"], d["stream"].tobytes()
+    rows = _pack_rows16(tab, sym)
+    c = lib.pconv_coder_new(None)
+    try:
+        assert lib.pconv_coder_start_encoder(c) == 0
+        half = len(sym) // 2                         # two calls: the state carries over like the int32 loop's
+        assert lib.pconv_coder_encodes_rows16(c, rows.ctypes.data, half) == 0
+        assert lib.pconv_coder_encodes_rows16(c, rows[half:].ctypes.data, len(sym) - half) == 0
+        assert lib.pconv_coder_end_encoder(c) == 0
+        n = ctypes_size()
+        p = lib.pconv_coder_bytes(c, n)
+        got = bytes(bytearray(p[i] for i in range(n._obj.value))) if n._obj.value else b""
+        assert got == gold
+        buf = np.frombuffer(gold, dtype=np.uint8).copy()
+        assert lib.pconv_coder_start_decoder_mem(c, buf.ctypes.data, len(buf)) == 0
+        out = np.zeros(max(len(sym), 1), dtype=np.int32)
+        assert lib.pconv_coder_decodes_rows16_i32(c, _pack_rows16(tab).ctypes.data, out.ctypes.data, len(sym)) == 0
+        assert (out[:len(sym)] == sym).all()
+    finally:
+        lib.pconv_coder_free(c)
+
+
+def ctypes_size():
+    import ctypes
+    return ctypes.byref(ctypes.c_size_t(0))
+
+
+def test_packed_rows_keep_entries_of_65536_exact():
+    """a row whose top bins are empty (c_k == 65536 for k < 8) is stored with a flag bit, not wrapped to 0: coding
+    a live symbol gives the int32 loop's bytes, coding an empty bin the same "zero frequency" error"""
+    from pseudocylindrical_convolution_amd import _native
+    lib = _native.coder_lib()
+    tab = np.array([[0, 100, 30000, 65000, 65536, 65536, 65536, 65536, 65536]] * 64, dtype=np.int32)
+    sym = (np.arange(64) % 4).astype(np.int32)
+    a, b = lib.pconv_coder_new(None), lib.pconv_coder_new(None)
+    try:
+        for c in (a, b):
+            assert lib.pconv_coder_start_encoder(c) == 0
+        assert lib.pconv_coder_encodes(a, tab.ctypes.data, 8, sym.ctypes.data, 64) == 0
+        assert lib.pconv_coder_encodes_rows16(b, _pack_rows16(tab, sym).ctypes.data, 64) == 0
+        out = []
+        for c in (a, b):
+            assert lib.pconv_coder_end_encoder(c) == 0
+            n = ctypes_size()
+            p = lib.pconv_coder_bytes(c, n)
+            out.append(bytes(bytearray(p[i] for i in range(n._obj.value))))
+        assert out[0] == out[1] and len(out[0]) > 4
+        bad = np.array([5], dtype=np.int32)      # an empty bin
+        assert lib.pconv_coder_start_encoder(a) == 0 and lib.pconv_coder_start_encoder(b) == 0
+        ra = lib.pconv_coder_encodes(a, tab.ctypes.data, 8, bad.ctypes.data, 1)
+        rb = lib.pconv_coder_encodes_rows16(b, _pack_rows16(tab[:1], bad).ctypes.data, 1)
+        assert ra == rb and ra < 0
+    finally:
+        lib.pconv_coder_free(a)
+        lib.pconv_coder_free(b)
