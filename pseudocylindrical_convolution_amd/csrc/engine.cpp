@@ -872,7 +872,8 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
   // Host-constrained rank: the runtime's waits (stream / event synchronisation of the drivers and the coder
   // threads) sleep on an interrupt instead of spinning.  A device-wide flag of this process -- one process per
   // GPU is the deployment model (test/trainDDP_Full.py:83-86); PCONV_ENGINE_BLOCKING_SYNC=0 / 1 forces it.
-  if (host_plan(nimg).blocking_sync) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+  if (host_plan(nimg).blocking_sync && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess)
+    (void)hipGetLastError();  // (a runtime that refuses the flag on a live context: keep spinning, leave no stale error)
   pconv_entropy_engine *e = new pconv_entropy_engine();
   e->npart = npart; e->ngroup = ngroup; e->h = h; e->w = w; e->nimg = nimg;
   e->bias = bias; e->nlevels = nlevels; e->total = total; e->beta = beta;

@@ -160,11 +160,20 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
     const int lim16 = (w + 2 * PAD - col0) * CIN / 4;     // whole pieces left in the buffer's row
     const int npiece = PR * row16;
     const size_t buf_pitch = (size_t)(w + 2 * PAD) * CIN;
+    // (piece p = p0 + tid: its patch row and place in the row advance with the round, no division per piece)
+    int pr = tid / row16, j = tid - pr * row16;
+    const int dpr = (WAVES * kWave) / row16, dj = (WAVES * kWave) - dpr * row16;
     for (int p0 = 0; p0 < npiece; p0 += WAVES * kWave) {
-      const int p = p0 + tid < npiece ? p0 + tid : npiece - 1;
-      const int pr = p / row16, j = p - pr * row16;
-      const float *src = xt + pr * buf_pitch + 4 * (j < lim16 ? j : lim16 - 1);
+      const bool in = p0 + tid < npiece;
+      const int prc = in ? pr : PR - 1, jc = in ? j : row16 - 1;  // (the tail re-reads the last piece)
+      const float *src = xt + prc * buf_pitch + 4 * (jc < lim16 ? jc : lim16 - 1);
       __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)(patch + (size_t)(p0 + wave * kWave) * 4), 16, 0, 0);
+      pr += dpr;
+      j += dj;
+      if (j >= row16) {
+        j -= row16;
+        pr++;
+      }
     }
     // the slack behind the (rounded) patch that over-long entries of the last rows may read
     const int rounded = (npiece + WAVES * kWave - 1) / (WAVES * kWave) * (WAVES * kWave) * 4;
@@ -311,22 +320,49 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   // way out: lane L holds outputs 16 mt + 4 (L >> 4) + r of position (row 2 rp + nt, column L & 15)
   const int col = col0 + 16 * ct + (lane & 15);
   if (col >= width) return;
+  // four consecutive outputs per accumulator tile: 8-byte pieces (a pixel is 168 bytes, an output quad starts at a
+  // multiple of 16: both 8-byte aligned); the whole schedule (no step range) skips the per-output range test
+  const bool whole = s_lo <= 0 && s_hi > g.h * g.npart + g.w + g.ngroup;  // (uniform)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const float *bset = bias + set * COUT, *sset = slope ? slope + set * COUT : nullptr;
 #pragma unroll
-  for (int nt = 0; nt < kNT; nt++) {
-    const int row = row0 + kNT * rp + nt;
-    const int plane = tile * h + row + col;
-    const size_t ob = ((((size_t)pn * g.npart + tile) * (h + 2 * pad_out) + row + pad_out) * (w + 2 * pad_out) + col + pad_out) * COUT;
+  for (int mt = 0; mt < kMT; mt++) {
+    const int out0 = 16 * mt + 4 * q;
+    if (out0 >= COUT) continue;  // (the last quads of the padded tile: lanes q = 3 of tile 2, and q = 2's second half below)
+    const bool second = out0 + 2 < COUT;
+    const f2 b01 = *reinterpret_cast<const f2 *>(bset + out0);
+    const f2 b23 = second ? *reinterpret_cast<const f2 *>(bset + out0 + 2) : (f2){0.f, 0.f};
+    f2 s01 = {1.f, 1.f}, s23 = {1.f, 1.f};  // (v * 1 is v)
+    if (sset) {
+      s01 = *reinterpret_cast<const f2 *>(sset + out0);
+      if (second) s23 = *reinterpret_cast<const f2 *>(sset + out0 + 2);
+    }
 #pragma unroll
-    for (int mt = 0; mt < kMT; mt++) {
+    for (int nt = 0; nt < kNT; nt++) {
+      const int row = row0 + kNT * rp + nt;
+      const int plane = tile * h + row + col;
+      const size_t ob = ((((size_t)pn * g.npart + tile) * (h + 2 * pad_out) + row + pad_out) * (w + 2 * pad_out) + col + pad_out) * COUT + out0;
+      f2 r01 = {0.f, 0.f}, r23 = {0.f, 0.f};
+      if (residual) {
+        r01 = *reinterpret_cast<const f2 *>(residual + ob);
+        if (second) r23 = *reinterpret_cast<const f2 *>(residual + ob + 2);
+      }
+      const f32x4 t = P3[mt * kNT + nt];
+      float v[4] = {t[0] + b01[0], t[1] + b01[1], t[2] + b23[0], t[3] + b23[1]};
+      const float sl[4] = {s01[0], s01[1], s23[0], s23[1]}, rs[4] = {r01[0], r01[1], r23[0], r23[1]};
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int out = 16 * mt + 4 * q + r;
-        const int s = plane + out / GO;
-        if (out < COUT && s >= s_lo && s < s_hi) {
-          float v = P3[mt * kNT + nt][r] + bias[set * COUT + out];
-          if (v < 0) v = v * (slope ? slope[set * COUT + out] : 1.f);
-          if (residual) v = v + residual[ob + out];
-          y[ob + out] = v;
+        if (v[r] < 0) v[r] = v[r] * sl[r];
+        if (residual) v[r] = v[r] + rs[r];
+      }
+      if (whole) {
+        *reinterpret_cast<f2 *>(y + ob) = (f2){v[0], v[1]};
+        if (second) *reinterpret_cast<f2 *>(y + ob + 2) = (f2){v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int step = plane + (out0 + r) / GO;
+          if (out0 + r < COUT && step >= s_lo && step < s_hi) y[ob + r] = v[r];
         }
       }
     }
@@ -352,16 +388,16 @@ int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int c
 // PCONV_EE_MFMA_NT); rows per tile must be a multiple of nt * rp_n
 // PCONV_EE_MFMA_WSRC=ring: the LDS-ring form of the one-row kernel (default: direct fetch)
 static bool mfma_direct(int nt) {
-  static const bool ring = getenv("PCONV_EE_MFMA_WSRC") && getenv("PCONV_EE_MFMA_WSRC")[0] == 'r';
+  const bool ring = getenv("PCONV_EE_MFMA_WSRC") && getenv("PCONV_EE_MFMA_WSRC")[0] == 'r';  // (per call: tests switch it)
   return nt == 1 && !ring;
 }
 
 int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves, int *nt) {
-  static const int wv = getenv("PCONV_EE_MFMA_WAVES") ? atoi(getenv("PCONV_EE_MFMA_WAVES")) : 4;
+  const int wv = getenv("PCONV_EE_MFMA_WAVES") ? atoi(getenv("PCONV_EE_MFMA_WAVES")) : 4;  // (per engine)
   // measured (MI355X, 4096x2048, one frame x 3 sets per launch, profiles/round5_entropy_mfma_variants.txt): one row per
   // wave 452 us per full launch (two rows: 474; eight waves per workgroup: 509 / 550), 591 / 715 us for a frame
   // in four step ranges
-  static const int nt_env = getenv("PCONV_EE_MFMA_NT") ? atoi(getenv("PCONV_EE_MFMA_NT")) : 1;
+  const int nt_env = getenv("PCONV_EE_MFMA_NT") ? atoi(getenv("PCONV_EE_MFMA_NT")) : 1;
   const int nw = wv == 8 ? 8 : 4;
   const int n = (nt_env == 1 || (h & 1)) ? 1 : 2;
   if (cin != 42 || h < n) return 0;

@@ -7,6 +7,7 @@
 // reuses it for all RB rows, so the tap table (20 B/column, L2 resident) costs
 // 20/RB bytes per output element.  Lanes map to consecutive output columns, so
 // stores are contiguous 256 B per wave.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -46,7 +47,7 @@ __device__ __forceinline__ float cubic_at(const float *row, const Tap &t, int pe
 __global__ __launch_bounds__(kBlock) void slice_kernel(
     const float *__restrict__ in, float *__restrict__ out, const int32_t *__restrict__ widths,
     const int32_t *__restrict__ tap_col, const float *__restrict__ tap_coef, int c, int height,
-    int width, int npart, int pad, int rb, long long ngroups) {
+    int width, int npart, int pad, int rb, long long ngroups, int vec4) {
   extern __shared__ float lds[];
   const int th_tile = height / npart;
   const int oh = th_tile + 2 * pad, ow = width + 2 * pad;
@@ -71,12 +72,34 @@ __global__ __launch_bounds__(kBlock) void slice_kernel(
     __syncthreads();
     const int valid = widths[pt];
     float *dst = out + (((size_t)(pn * npart + pt) * c + pc) * oh + th + pad) * ow + pad;
-    for (int tw = threadIdx.x; tw < width; tw += kBlock) {
-      if (tw < valid) {
-        const Tap t = load_tap(tap_col, tap_coef, (size_t)pt * width + tw);
-        for (int r = 0; r < rb; r++) dst[(size_t)r * ow + tw] = cubic_at(lds + r * width, t, width);
-      } else {
-        for (int r = 0; r < rb; r++) dst[(size_t)r * ow + tw] = 0.f;
+    if (vec4) {
+      // four consecutive output columns per lane: one 16-byte store per row (the tap records of the four columns
+      // are four 16-byte loads + one of their columns), a quarter of the memory instructions of the scalar form
+      for (int tw = threadIdx.x * 4; tw < width; tw += kBlock * 4) {
+        const size_t e = (size_t)pt * width + tw;
+        const int4 cols = *reinterpret_cast<const int4 *>(tap_col + e);
+        const int cc[4] = {cols.x, cols.y, cols.z, cols.w};
+        Tap t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float4 cf = *reinterpret_cast<const float4 *>(tap_coef + (e + k) * 4);
+          t[k].col = cc[k], t[k].c0 = cf.x, t[k].c1 = cf.y, t[k].c2 = cf.z, t[k].c3 = cf.w;
+        }
+        for (int r = 0; r < rb; r++) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = tw + k < valid ? cubic_at(lds + r * width, t[k], width) : 0.f;
+          *reinterpret_cast<float4 *>(dst + (size_t)r * ow + tw) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    } else {
+      for (int tw = threadIdx.x; tw < width; tw += kBlock) {
+        if (tw < valid) {
+          const Tap t = load_tap(tap_col, tap_coef, (size_t)pt * width + tw);
+          for (int r = 0; r < rb; r++) dst[(size_t)r * ow + tw] = cubic_at(lds + r * width, t, width);
+        } else {
+          for (int r = 0; r < rb; r++) dst[(size_t)r * ow + tw] = 0.f;
+        }
       }
     }
   }
@@ -86,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void slice_kernel(
 __global__ __launch_bounds__(kBlock) void uslice_kernel(
     const float *__restrict__ in, float *__restrict__ out, const int32_t *__restrict__ widths,
     const int32_t *__restrict__ tap_col, const float *__restrict__ tap_coef, int c, int h,
-    int width, int npart, int pad, int rb, long long ngroups) {
+    int width, int npart, int pad, int rb, long long ngroups, int vec4) {
   extern __shared__ float lds[];
   const int h_out = h * npart;
   const int ih = h + 2 * pad, iw = width + 2 * pad;
@@ -105,15 +128,39 @@ __global__ __launch_bounds__(kBlock) void uslice_kernel(
       for (int i = threadIdx.x; i < valid; i += kBlock) lds[r * width + i] = src[(size_t)r * iw + i];
     __syncthreads();
     float *dst = out + (size_t)row0 * width;
-    for (int tw = threadIdx.x; tw < width; tw += kBlock) {
-      const Tap t = load_tap(tap_col, tap_coef, (size_t)pb * width + tw);
-      for (int r = 0; r < rb; r++) dst[(size_t)r * width + tw] = cubic_at(lds + r * width, t, valid);
+    if (vec4) {
+      for (int tw = threadIdx.x * 4; tw < width; tw += kBlock * 4) {
+        const size_t e = (size_t)pb * width + tw;
+        const int4 cols = *reinterpret_cast<const int4 *>(tap_col + e);
+        const int cc[4] = {cols.x, cols.y, cols.z, cols.w};
+        Tap t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float4 cf = *reinterpret_cast<const float4 *>(tap_coef + (e + k) * 4);
+          t[k].col = cc[k], t[k].c0 = cf.x, t[k].c1 = cf.y, t[k].c2 = cf.z, t[k].c3 = cf.w;
+        }
+        for (int r = 0; r < rb; r++) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = cubic_at(lds + r * width, t[k], valid);
+          *reinterpret_cast<float4 *>(dst + (size_t)r * width + tw) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    } else {
+      for (int tw = threadIdx.x; tw < width; tw += kBlock) {
+        const Tap t = load_tap(tap_col, tap_coef, (size_t)pb * width + tw);
+        for (int r = 0; r < rb; r++) dst[(size_t)r * width + tw] = cubic_at(lds + r * width, t, valid);
+      }
     }
   }
 }
 
 int rows_per_block(int tile_rows, int width) {
-  int rb = kMaxRows;
+  // PCONV_RESAMPLE_ROWS (1 / 2 / 4): rows a workgroup stages -- fewer rows = less LDS per workgroup = more of them
+  // resident per CU against 20 / rows bytes of tap table per output element
+  // (measured, 1x3x2048x4096: 4 rows 3.47 / 3.20 TB/s slice / uslice, 2 rows 3.92 / 3.71, 1 row 3.79 / 3.51)
+  static const int cap = getenv("PCONV_RESAMPLE_ROWS") ? atoi(getenv("PCONV_RESAMPLE_ROWS")) : 2;
+  int rb = cap >= 1 && cap <= kMaxRows ? cap : kMaxRows;
   while (rb > 1 && (tile_rows % rb != 0 || (size_t)rb * width * 4 > 64 * 1024)) rb >>= 1;
   return rb;
 }
@@ -130,9 +177,12 @@ extern "C" int pconv_sphere_slice(const float *in, float *out, const int32_t *wi
   const int rb = rows_per_block(height / npart, width);
   const long long ngroups = (long long)n * c * height / rb;
   const unsigned grid = (unsigned)(ngroups < 256 * 16 ? ngroups : 256 * 16);
+  // 16-byte stores / tap loads: whole quads per row, rows 16-byte aligned (no pad offset), aligned tensors
+  const int vec4 = (width % 4 == 0) && pad == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(tap_col) |
+                                                      reinterpret_cast<uintptr_t>(tap_coef)) & 15) == 0;
   hipLaunchKernelGGL(slice_kernel, dim3(grid), dim3(kBlock), (size_t)rb * width * 4,
                      as_stream(stream), in, out, widths, tap_col, tap_coef, c, height, width,
-                     npart, pad, rb, ngroups);
+                     npart, pad, rb, ngroups, vec4);
   PCONV_LAUNCH_CHECK("sphere_slice");
   return PCONV_OK;
 }
@@ -146,9 +196,11 @@ extern "C" int pconv_sphere_uslice(const float *in, float *out, const int32_t *w
   const int rb = rows_per_block(h, width);
   const long long ngroups = (long long)n * c * h * npart / rb;
   const unsigned grid = (unsigned)(ngroups < 256 * 16 ? ngroups : 256 * 16);
+  const int vec4 = (width % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(tap_col) |
+                                          reinterpret_cast<uintptr_t>(tap_coef)) & 15) == 0;
   hipLaunchKernelGGL(uslice_kernel, dim3(grid), dim3(kBlock), (size_t)rb * width * 4,
                      as_stream(stream), in, out, widths, tap_col, tap_coef, c, h, width, npart,
-                     pad, rb, ngroups);
+                     pad, rb, ngroups, vec4);
   PCONV_LAUNCH_CHECK("sphere_uslice");
   return PCONV_OK;
 }

@@ -59,3 +59,18 @@ def test_odd_row_counts_fall_back_to_the_vector_kernel(hip_backend, monkeypatch)
     sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(9)).float().cuda()
     sym = ent.fill(sym).contiguous()
     assert _encode(ent, sym, h, w, n, "mfma", monkeypatch) == _encode(ent, sym, h, w, n, "valu", monkeypatch)
+
+
+@pytest.mark.parametrize("nt,waves,wsrc", [(1, 4, "direct"), (1, 4, "ring"), (2, 4, "ring"), (1, 8, "direct"), (2, 8, "ring")])
+def test_measured_variants_of_the_matrix_core_kernel_agree(hip_backend, monkeypatch, nt, waves, wsrc):
+    """rows per wave x waves per workgroup x where the weight fragments come from (PCONV_EE_MFMA_NT / _WAVES / _WSRC:
+    the variants of profiles/round5_entropy_mfma_variants.txt) all write the vector kernel's streams"""
+    ent = _ent(13)
+    h, w, n = 8, 192, 1
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(17)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    ref = _encode(ent, sym, h, w, n, "valu", monkeypatch, ranges=2)
+    monkeypatch.setenv("PCONV_EE_MFMA_NT", str(nt))
+    monkeypatch.setenv("PCONV_EE_MFMA_WAVES", str(waves))
+    monkeypatch.setenv("PCONV_EE_MFMA_WSRC", wsrc)
+    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=2) == ref
