@@ -278,7 +278,7 @@ struct Group {
   EeGeom geom;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
-  std::vector<int> enc_bounds;         // encoder: step ranges (see encode_tables)
+  std::vector<int> enc_bounds;         // encoder: step ranges (set_encode_ranges, encode_range)
   hipEvent_t enc_done[8] = {nullptr};  // ... and "this range's rows are on the host"
   float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
   float *act[kLayers] = {nullptr};  // (3*nimg*npart, h+2p, w+2p, 3G), persistent across steps
@@ -709,48 +709,51 @@ struct pconv_entropy_engine {
   size_t image_symbols() const { return (size_t)npart * ngroup * h * w; }
 
   // encoder, GPU part of one group: CDF rows and labels of all its symbols -> pinned host memory
-  int encode_tables(Group &g, const float *symbols) {
-    const int cols = nlevels + 1;
+  // encoder, GPU part of one group, first half: all symbols are known -- fill the context once; the causal masks
+  // keep every step from seeing more than DInput2 would have given it
+  int encode_prologue(Group &g, const float *symbols) {
     const float *sym = symbols + (size_t)g.first * image_symbols();
-    // all symbols are known: fill the context once; the causal masks keep every
-    // step from seeing more than DInput2 would have given it
     PC_TRY(clear(g));
     PC_TRY(ee_fill_ctx(&g.geom, sym, g.ctx, -bias, g.stream));
     PC_TRY(ee_halo_bulk(&g.geom, g.ctx, ngroup, g.nimg, g.stream));
-    const size_t row = g.step_row[nsteps];
-    if (stepwise_encoder) {
-      for (int s = 0; s < nsteps; s++) {
-        const Window cur = window(s);
-        PC_TRY(network_step(g, s, cur));
-        PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], sym, g.tables_d + (size_t)g.step_row[s] * cols,
-                         g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, nullptr, nullptr, 0, 0,
-                         g.stream));
-      }
-    } else {
-      // Step ranges (g.enc_bounds: 0 = b_0 < b_1 < ... = nsteps): a range's rows go to the host as soon as they
-      // exist and an event says so, so that the arithmetic coder works on range k while the GPU is on range k + 1.
-      // One range for the groups whose coding hides behind the next group's GPU work anyway; the call's LAST
-      // group in several: its coding was the encoder's tail (15 ms of GPU idle per 8-frame step).
-      const int nrange = (int)g.enc_bounds.size() - 1;
-      for (int k = 0; k < nrange; k++) {
-        const int s_lo = g.enc_bounds[k], s_hi = g.enc_bounds[k + 1];
-        int first = 0, count = 0;
-        step_range_entries(s_lo, s_hi, &first, &count);
-        PC_TRY(network_bulk(g, s_lo, s_hi));
-        PC_TRY(ee_tables_bulk(&g.geom, g.act[kLayers - 1], sym, g.tables_d, g.labels_d, nlevels, bias, total, beta, first,
-                              count, s_lo, s_hi, packed, g.stream));
-        const size_t r0 = g.step_row[s_lo], r1 = g.step_row[s_hi];
-        if (r1 > r0) {
-          const size_t rb = row_bytes();
-          HIP_TRY(hipMemcpyAsync((char *)g.tables_h + r0 * rb, (const char *)g.tables_d + r0 * rb, (r1 - r0) * rb,
-                                 hipMemcpyDeviceToHost, g.stream));
-          if (!packed)
-            HIP_TRY(hipMemcpyAsync(g.labels_h + r0, g.labels_d + r0, (r1 - r0) * 4, hipMemcpyDeviceToHost, g.stream));
-        }
-        HIP_TRY(hipEventRecord(g.enc_done[k], g.stream));
-      }
-      return PCONV_OK;
+    return PCONV_OK;
+  }
+
+  // ... second half, step range k of g.enc_bounds (0 = b_0 < b_1 < ... = nsteps): the range's CDF rows and labels
+  // -> pinned host memory, then the event that says so -- the arithmetic coder works on range k while the GPU is
+  // on range k + 1 (of this group or of another one)
+  int encode_range(Group &g, const float *symbols, int k) {
+    const float *sym = symbols + (size_t)g.first * image_symbols();
+    const int s_lo = g.enc_bounds[k], s_hi = g.enc_bounds[k + 1];
+    int first = 0, count = 0;
+    step_range_entries(s_lo, s_hi, &first, &count);
+    PC_TRY(network_bulk(g, s_lo, s_hi));
+    PC_TRY(ee_tables_bulk(&g.geom, g.act[kLayers - 1], sym, g.tables_d, g.labels_d, nlevels, bias, total, beta, first, count,
+                          s_lo, s_hi, packed, g.stream));
+    const size_t r0 = g.step_row[s_lo], r1 = g.step_row[s_hi];
+    if (r1 > r0) {
+      const size_t rb = row_bytes();
+      HIP_TRY(hipMemcpyAsync((char *)g.tables_h + r0 * rb, (const char *)g.tables_d + r0 * rb, (r1 - r0) * rb,
+                             hipMemcpyDeviceToHost, g.stream));
+      if (!packed)
+        HIP_TRY(hipMemcpyAsync(g.labels_h + r0, g.labels_d + r0, (r1 - r0) * 4, hipMemcpyDeviceToHost, g.stream));
     }
+    HIP_TRY(hipEventRecord(g.enc_done[k], g.stream));
+    return PCONV_OK;
+  }
+
+  // the debugging encoder: step by step like the decoder (PCONV_ENGINE_STEPWISE_ENCODER; int32 rows)
+  int encode_stepwise(Group &g, const float *symbols) {
+    const int cols = nlevels + 1;
+    const float *sym = symbols + (size_t)g.first * image_symbols();
+    for (int s = 0; s < nsteps; s++) {
+      const Window cur = window(s);
+      PC_TRY(network_step(g, s, cur));
+      PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], sym, g.tables_d + (size_t)g.step_row[s] * cols,
+                       g.labels_d + g.step_row[s], cur.lo, cur.len, s, nlevels, bias, total, beta, nullptr, nullptr, 0, 0,
+                       g.stream));
+    }
+    const size_t row = g.step_row[nsteps];
     HIP_TRY(hipMemcpyAsync(g.tables_h, g.tables_d, row * cols * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(g.labels_h, g.labels_d, row * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipEventRecord(g.enc_done[0], g.stream));
@@ -957,13 +960,45 @@ int pconv_ee_encode_begin(pconv_entropy_engine *e, const float *symbols, void *s
   // PCONV_ENGINE_ENCODE_RANGES: step ranges of the call's last group (default 4; 1 = as one piece)
   const int last_ranges = e->encode_ranges > 0 ? e->encode_ranges
                           : (getenv("PCONV_ENGINE_ENCODE_RANGES") ? atoi(getenv("PCONV_ENGINE_ENCODE_RANGES")) : 4);
-  for (size_t k = 0; k < e->groups.size(); k++) {
-    Group &g = e->groups[k];
-    e->set_encode_ranges(g, (k + 1 == e->groups.size() && !e->stepwise_encoder) ? last_ranges : 1);
-    hipStream_t own = g.stream;
-    g.stream = caller;
-    const int rc = e->encode_tables(g, symbols);
-    g.stream = own;
+  // A call whose coding nothing hides (ranges asked for) takes ALL its groups through the ranges together, range by
+  // range: every frame's coder starts after the first range of its group, and the last frame's GPU work no longer
+  // ends a whole frame's coding before its coder does (r5: the tail behind an 8-frame encode 9 -> 3 ms).
+  // PCONV_ENGINE_ENCODE_INTERLEAVE=0: group by group, ranges on the last group only (the round-4 order).
+  const bool interleave = last_ranges > 1 && e->groups.size() > 1 && !e->stepwise_encoder &&
+                          !(getenv("PCONV_ENGINE_ENCODE_INTERLEAVE") && atoi(getenv("PCONV_ENGINE_ENCODE_INTERLEAVE")) == 0);
+  {
+    std::vector<hipStream_t> own;
+    for (Group &g : e->groups) {
+      own.push_back(g.stream);
+      g.stream = caller;
+    }
+    int rc = PCONV_OK;
+    const size_t ng = e->groups.size();
+    if (e->stepwise_encoder) {
+      for (size_t k = 0; k < ng && rc >= 0; k++) {
+        e->set_encode_ranges(e->groups[k], 1);
+        rc = e->encode_prologue(e->groups[k], symbols);
+        if (rc >= 0) rc = e->encode_stepwise(e->groups[k], symbols);
+      }
+    } else if (interleave) {
+      size_t most = 0;
+      for (size_t k = 0; k < ng && rc >= 0; k++) {
+        e->set_encode_ranges(e->groups[k], last_ranges);
+        most = std::max(most, e->groups[k].enc_bounds.size() - 1);
+        rc = e->encode_prologue(e->groups[k], symbols);
+      }
+      for (size_t r = 0; r < most && rc >= 0; r++)
+        for (size_t k = 0; k < ng && rc >= 0; k++)
+          if (r + 1 < e->groups[k].enc_bounds.size()) rc = e->encode_range(e->groups[k], symbols, (int)r);
+    } else {
+      for (size_t k = 0; k < ng && rc >= 0; k++) {
+        Group &g = e->groups[k];
+        e->set_encode_ranges(g, k + 1 == ng ? last_ranges : 1);
+        rc = e->encode_prologue(g, symbols);
+        for (size_t r = 0; r + 1 < g.enc_bounds.size() && rc >= 0; r++) rc = e->encode_range(g, symbols, (int)r);
+      }
+    }
+    for (size_t k = 0; k < ng; k++) e->groups[k].stream = own[k];
     if (rc < 0) e->distrust_buffers();
     PC_TRY(rc);
   }

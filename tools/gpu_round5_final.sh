@@ -25,6 +25,8 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 1 --warmup 0 --prime 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err || tail -5 $O/bench_under_rocprof.err
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+python3 $R/tools/gpu_idle_map.py $(find /tmp/prof_bench -name "*kernel_trace.csv" | head -1) 12 50 > $O/bench_idle_map.txt 2>&1 || true
+head -8 $O/bench_idle_map.txt
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   i=$((i+1)); rm -rf /tmp/pmc_b_$i
