@@ -535,7 +535,13 @@ struct pconv_entropy_engine {
         if (!blk.empty()) {
           HIP_TRY(hipMalloc(&mfma_blocks_d, blk.size() * 4));
           HIP_TRY(hipMemcpy(mfma_blocks_d, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
-          for (int l = 1; l < kLayers; l++) HIP_TRY(hipMalloc(&lwf[l], (size_t)ee_mfma_packed_floats(3, 3 * ngroup) * 4));
+          // (the input layer -- 14 channels, one context for the three sets -- only in the one-row direct form;
+          // PCONV_EE_BULK0=valu keeps the vector kernel for it)
+          const char *env0 = getenv("PCONV_EE_BULK0");
+          const char *wsrc = getenv("PCONV_EE_MFMA_WSRC");
+          const bool layer0 = nt == 1 && !(wsrc && wsrc[0] == 'r') && !(env0 && env0[0] == 'v');
+          for (int l = layer0 ? 0 : 1; l < kLayers; l++)
+            HIP_TRY(hipMalloc(&lwf[l], (size_t)ee_mfma_packed_floats(3, layer_cin(l)) * 4));
           mfma_nblocks = (int)(blk.size() / 4);
           mfma_rp = rp, mfma_ct = ct, mfma_waves = wv, mfma_nt = nt;
         }
@@ -695,7 +701,7 @@ struct pconv_entropy_engine {
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
       if (mfma_waves && lwf[l] && nblist == 0) continue;  // (no block of this range: nothing to evaluate)
       if (mfma_waves && lwf[l])
-        PC_TRY(ee_conv_bulk_mfma(&g.geom, blist, nblist, mfma_rp, mfma_ct, mfma_waves, mfma_nt, in, 0, lwf[l], lb[l],
+        PC_TRY(ee_conv_bulk_mfma(&g.geom, blist, nblist, mfma_rp, mfma_ct, mfma_waves, mfma_nt, in, l == 0, lwf[l], lb[l],
                                  la[l], res, g.act[l], layer_cin(l), hid, l == kLayers - 1 ? 0 : kPad, s_lo, s_hi,
                                  g.stream));
       else
@@ -904,7 +910,8 @@ int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, 
   PC_TRY(ee_pack_weight(weight, e->lw[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, layer == 0 ? 5 : 6,
                         stream));
   if (e->lwf[layer])
-    PC_TRY(ee_pack_weight_mfma(weight, e->lwf[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, 6, stream));
+    PC_TRY(ee_pack_weight_mfma(weight, e->lwf[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, layer == 0 ? 5 : 6,
+                               stream));
   e->lb[layer] = bias;
   e->la[layer] = slope;
   e->bound[layer] = true;

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   // piece: behind a guarded load the compiler's wait-count state of the skipped path made it wait for the load
   // it had just issued.
   const float *wset = wfrag + (size_t)set * 64 * FRAG;
-  constexpr int PIECE = FRAG / (WAVES * kWave);  // floats per thread and class
-  static_assert(PIECE * WAVES * kWave == FRAG && (PIECE == 4 || PIECE == 2), "whole pieces");
+  constexpr int PIECE = DIRECT ? 4 : FRAG / (WAVES * kWave);  // floats per thread and class (ring form only)
+  static_assert(DIRECT || (PIECE * WAVES * kWave == FRAG && (PIECE == 4 || PIECE == 2)), "whole pieces");
   typedef float piece_t __attribute__((ext_vector_type(PIECE)));
   auto fetch_class = [&](int i) { return *reinterpret_cast<const piece_t *>(wset + (size_t)i * FRAG + tid * PIECE); };
   auto store_class = [&](int i, const piece_t &v) {
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   // PIPE (one row per wave: registers to spare): the operands of class i + 1 are read from LDS while the matrix
   // instructions of class i run, so the weight ring runs one class further ahead
   constexpr bool PIPE = kNT == 1;
-  piece_t wnext = fetch_class(0);
+  piece_t wnext = {};
   if (!DIRECT) {
+    wnext = fetch_class(0);
     store_class(0, wnext);
     if (PIPE) store_class(1, fetch_class(1));
     wnext = fetch_class(PIPE ? 2 : 1);
@@ -400,7 +401,7 @@ int ee_mfma_block_shape(int h, int cin, int *rp_n, int *ct_n, int *waves, int *n
   const int nt_env = getenv("PCONV_EE_MFMA_NT") ? atoi(getenv("PCONV_EE_MFMA_NT")) : 1;
   const int nw = wv == 8 ? 8 : 4;
   const int n = (nt_env == 1 || (h & 1)) ? 1 : 2;
-  if (cin != 42 || h < n) return 0;
+  if ((cin != 42 && cin != 14) || h < n) return 0;
   const int rows = h / n;  // wave rows per tile
   int rp = rows;
   const int cap = nw == 8 ? 4 : (n == 1 ? 4 : 2);
@@ -416,14 +417,15 @@ int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n
                       int shared_input, const float *wfrag, const float *bias, const float *slope,
                       const float *residual, float *y, int cin, int cout, int pad_out, int s_lo, int s_hi,
                       void *stream) {
-  PCONV_REQUIRE(cin == 42 && cout == 42 && g->ngroup == 14, "ee_conv_bulk_mfma: 42 -> 42 channels only");
+  PCONV_REQUIRE((cin == 42 || cin == 14) && cout == 42 && g->ngroup == 14, "ee_conv_bulk_mfma: 14 / 42 -> 42 channels only");
+  PCONV_REQUIRE(cin == 42 || (nt == 1 && mfma_direct(nt)), "ee_conv_bulk_mfma: the input layer takes the one-row direct form");
   PCONV_REQUIRE(rp_n > 0 && ct_n > 0 && rp_n * ct_n == waves && (waves == 4 || waves == 8) && (nt == 1 || nt == 2) &&
                     g->h % (nt * rp_n) == 0,
                 "ee_conv_bulk_mfma: bad block shape");
   PCONV_REQUIRE(s_lo < s_hi && nblocks > 0, "ee_conv_bulk_mfma: bad range");
   // ring + patch, the patch rounded up to whole DMA rounds of the workgroup (16 bytes per thread)
   const size_t round = (size_t)waves * kWave * 16;
-  const size_t patch_bytes = ((size_t)(nt * rp_n + 4) * (16 * ct_n + 4) * 42 * sizeof(float) + round - 1) / round * round;
+  const size_t patch_bytes = ((size_t)(nt * rp_n + 4) * (16 * ct_n + 4) * cin * sizeof(float) + round - 1) / round * round;
   const bool direct = mfma_direct(nt);
   const size_t smem = (direct ? 0 : (size_t)kRing * frag_floats(42) * sizeof(float)) + patch_bytes + kPatchSlack * sizeof(float);
   PCONV_REQUIRE(smem <= 160 * 1024, "ee_conv_bulk_mfma: block needs %zu bytes of LDS", smem);
@@ -431,13 +433,14 @@ int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n
   PCONV_REQUIRE(grid.y <= 65535u, "ee_conv_bulk_mfma: too many images for one launch");
   typedef void (*kernel_t)(EeGeom, const int4 *, int, int, const float *, int, const float *, const float *, const float *,
                            const float *, float *, int, int, int);
-  const int kind = direct ? 4 + (waves == 8) : (waves == 8 ? 2 : 0) + (nt == 1 ? 1 : 0);
-  static const kernel_t kernels[6] = {ee_conv_bulk_mfma_kernel<42, 4, 2, false>, ee_conv_bulk_mfma_kernel<42, 4, 1, false>,
+  const int kind = cin == 14 ? 6 + (waves == 8) : direct ? 4 + (waves == 8) : (waves == 8 ? 2 : 0) + (nt == 1 ? 1 : 0);
+  static const kernel_t kernels[8] = {ee_conv_bulk_mfma_kernel<42, 4, 2, false>, ee_conv_bulk_mfma_kernel<42, 4, 1, false>,
                                       ee_conv_bulk_mfma_kernel<42, 8, 2, false>, ee_conv_bulk_mfma_kernel<42, 8, 1, false>,
-                                      ee_conv_bulk_mfma_kernel<42, 4, 1, true>,  ee_conv_bulk_mfma_kernel<42, 8, 1, true>};
+                                      ee_conv_bulk_mfma_kernel<42, 4, 1, true>,  ee_conv_bulk_mfma_kernel<42, 8, 1, true>,
+                                      ee_conv_bulk_mfma_kernel<14, 4, 1, true>,  ee_conv_bulk_mfma_kernel<14, 8, 1, true>};
   {
     // the dynamic-LDS limit is a per-device attribute of the function (conv.hip)
-    static std::atomic<unsigned long long> raised[6];
+    static std::atomic<unsigned long long> raised[8];
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) device = 0;
     const unsigned long long bit = 1ULL << (device & 63);

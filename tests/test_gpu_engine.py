@@ -226,3 +226,38 @@ def test_engine_buffers_are_zeroed_once_not_per_call(hip_backend):
     sym = fresh.symbols(b)
     assert torch.equal(used._engine("dec", sym.shape[2], sym.shape[3], 2).decode(sb), sym)
     assert torch.equal(used.decode(sb, 512, 1024), fresh.decode(sb, 512, 1024))
+
+
+def test_host_constrained_plan_decodes_the_same_symbols(hip_backend, monkeypatch, tmp_path):
+    """A rank with a small share of the host (cgroup quota / LOCAL_WORLD_SIZE below frames + 1: csrc/engine.cpp
+    host_plan) decodes with at most one group per CPU, the drivers decoding their groups' frames alone, on the
+    host-driven chain: same symbols as the plan of a rank that owns the host, same streams from the encoder."""
+    from pseudocylindrical_convolution_amd.engine import EntropyEngine
+    enc, _ = _codec()
+    ent = enc.ent
+    h, w, n = 4, 128, 5
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(23)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    for name in ("PCONV_ENGINE_GROUPS", "PCONV_ENGINE_WORKERS", "PCONV_ENGINE_CHAIN", "PCONV_ENGINE_BLOCKING_SYNC",
+                 "PCONV_CGROUP_CPU_MAX", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(name, raising=False)
+    roomy = EntropyEngine(ent, h, w, n, "cuda:0")
+    streams = roomy.encode(sym)
+    assert torch.equal(roomy.decode(streams), sym)
+    quota = tmp_path / "cpu.max"
+    quota.write_text("1600000 100000")                       # 16 CPUs ...
+    monkeypatch.setenv("PCONV_CGROUP_CPU_MAX", str(quota))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")              # ... shared by 8 ranks: 2 per rank, 5 frames
+    monkeypatch.setenv("PCONV_ENGINE_BLOCKING_SYNC", "0")    # (the device-wide wait policy stays as it is for the other tests)
+    lib = roomy.lib
+    import ctypes
+    plan = [ctypes.c_int(-1) for _ in range(4)]
+    assert lib.pconv_ee_host_plan(n, *[ctypes.addressof(v) for v in plan]) == 0
+    assert [v.value for v in plan[:3]] == [min(2, lib.pconv_ee_host_cpus()), 1, 0]
+    tight = EntropyEngine(ent, h, w, n, "cuda:0")
+    assert tight.encode(sym) == streams
+    assert torch.equal(tight.decode(streams), sym)
+    # one CPU: a single group, one thread
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
+    one = EntropyEngine(ent, h, w, n, "cuda:0")
+    assert torch.equal(one.decode(streams), sym)
