@@ -446,6 +446,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", default="2048x4096",
                     help="HxW of the CPU baseline sample (default: the metric frame, ~80 s on a 16-core share; 1024x2048: ~20 s)")
     ap.add_argument("--no-check", action="store_true", help="skip the round-trip / stationarity assertions")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the N-process path on a box with ONE GPU: every rank uses cuda:0 (gloo for the "
+                         "metric reduction: RCCL refuses two ranks on one device).  The ranks share the GPU, so `value` is "
+                         "not a scaling figure; it shows the multi-process path end to end on the HIP engine (launcher, "
+                         "pinning, host plan by LOCAL_WORLD_SIZE, reduction) and the host-side contention of N ranks")
     ap.add_argument("--emulate-local-world", type=int, default=0, metavar="N",
                     help="ONE real rank on one GPU with the host share rank 0 of N ranks on this node would get at "
                          "best: pinned to cgroup quota / N CPUs, LOCAL_WORLD_SIZE=N for the engine's thread / spin "
@@ -481,15 +486,19 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         args.first_frame = rank
         args.frame_stride = world
         args.frames_per_gpu = len(range(rank, args.frames_total, world))
+    share = bool(getattr(args, "share_gpu", False)) and on_gpu
+    if share:
+        dist_backend = "gloo"
+    local_dev = 0 if share else local
     if on_gpu:
-        torch.cuda.set_device(local)   # before the first HIP call of this rank
+        torch.cuda.set_device(local_dev)   # before the first HIP call of this rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=dist_backend)
-    dev = "cuda:%d" % local if on_gpu else "cpu"
+    dev = "cuda:%d" % local_dev if on_gpu else "cpu"
     n_joined = dist.get_world_size() if world > 1 else 1
 
-    load = (workload_cls or WORKLOADS[args.mode])(args, rank, local, dev)
+    load = (workload_cls or WORKLOADS[args.mode])(args, rank, local_dev, dev)
 
     def fence():
         if on_gpu:
@@ -530,7 +539,7 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     from pseudocylindrical_convolution_amd import sharding
     local_sums = {"pixels": load.pixels_per_step() * args.steps, "bits": float(load.bits), "frames": float(load.F)}
     local_sums.update(extra)
-    totals, elapsed = sharding.reduce_metrics(local_sums, elapsed, dev)
+    totals, elapsed = sharding.reduce_metrics(local_sums, elapsed, "cpu" if share else dev)
 
     out = None
     if rank == 0:
@@ -582,6 +591,8 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
             config["frames_total"] = args.frames_total
         if emulate:
             config["emulated_local_world"] = emulate
+        if share:
+            config["share_gpu"] = "REHEARSAL: %d ranks on ONE GPU (gloo); not a scaling figure" % n_joined
         if load.name == "codec":
             config["bpp"] = round(totals["bits"] / (frames_total * load.H * load.W), 4)
             if not args.no_check:

@@ -53,12 +53,18 @@ def test_matrix_core_encoder_in_one_piece_and_in_step_ranges(hip_backend, monkey
         assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=r) == ref
 
 
-def test_odd_row_counts_fall_back_to_the_vector_kernel(hip_backend, monkeypatch):
+def test_odd_row_counts_take_one_row_blocks(hip_backend, monkeypatch):
+    """three rows per tile: blocks of one row x 64 columns (one row per wave); with two rows per wave asked for
+    (PCONV_EE_MFMA_NT=2) the block shape still falls back to one"""
     ent = _ent()
     h, w, n = 3, 64, 1
     sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(9)).float().cuda()
     sym = ent.fill(sym).contiguous()
-    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch) == _encode(ent, sym, h, w, n, "valu", monkeypatch)
+    ref = _encode(ent, sym, h, w, n, "valu", monkeypatch)
+    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch) == ref
+    monkeypatch.setenv("PCONV_EE_MFMA_NT", "2")
+    monkeypatch.setenv("PCONV_EE_MFMA_WSRC", "ring")
+    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch) == ref
 
 
 @pytest.mark.parametrize("nt,waves,wsrc", [(1, 4, "direct"), (1, 4, "ring"), (2, 4, "ring"), (1, 8, "direct"), (2, 8, "ring")])
