@@ -1,4 +1,4 @@
-// Encoder ("bulk") form of a hidden layer of the entropy network on the fp32 matrix cores.
+// Encoder ("bulk") form of a layer of the entropy network on the fp32 matrix cores.
 //
 // Same numbers as ee_conv_bulk_kernel / ee_step_kernel (entropy_engine.hip), bit for bit: the
 // published order of the masked 5 x 5 convolution (entropy.hip; the reference:
@@ -19,13 +19,20 @@
 //
 // Work split.  A workgroup takes a block of BR rows x BC columns of one tile of one replica
 // (set x image) and stages its (BR + 4) x (BC + 4) x CIN patch of the channels-last padded
-// input in LDS ONCE (the vector kernel gathers every window from L2: 10.85 M L2 requests per
-// launch, "waits on its window gathers", profiles/round4_bench_pmc.json).  A wave owns two
-// stacked rows x 16 columns = two position tiles (matrix columns) and all 48 (42) outputs =
-// three output tiles (matrix rows): 6 accumulator tiles per class, 30 MFMAs per class.  The
-// weights come pre-packed as MFMA A-fragments in class order (ee_pack_weight_mfma: 4 KB per
-// class and set), streamed through a 4-slot LDS ring two classes ahead (register-staged), one
-// barrier per class (~1000 matrix cycles per wave).
+// input in LDS ONCE, by LDS-DMA (the vector kernel gathers every window from L2: 10.85 M L2
+// requests per launch, "waits on its window gathers", profiles/round4_bench_pmc.json).  A wave
+// owns kNT stacked rows x 16 columns = kNT position tiles (matrix columns) and all 48 (42)
+// outputs = three output tiles (matrix rows).  The weights come pre-packed as MFMA
+// A-fragments in class order (ee_pack_weight_mfma: 4 KB per class and set).  Forms (measured:
+// profiles/round5_entropy_mfma_variants.txt; PCONV_EE_MFMA_NT / _WAVES / _WSRC):
+//   default   one row per wave, four waves: 15 MFMAs per class and wave, 144 registers (three
+//             waves per SIMD); fragments straight from global memory into registers and the
+//             patch entries from LDS, both for class i + 1 under class i's MFMAs; no barrier
+//             after the prologue.  Also takes the 14-channel input layer.
+//   ring      the same with the fragments through a 4-slot LDS ring (register-staged two
+//             classes ahead, one barrier per class): level with the default.
+//   two rows  30 MFMAs per class and wave (every fragment feeds two), 250 registers, two waves
+//             per SIMD, ring only: 5-10 % slower.
 //
 // The causal masks make a (position, group) output independent of everything the decoder
 // would not have yet, so -- like ee_conv_bulk_kernel -- the kernel may evaluate ALL groups of
