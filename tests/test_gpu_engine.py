@@ -261,3 +261,34 @@ def test_host_constrained_plan_decodes_the_same_symbols(hip_backend, monkeypatch
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
     one = EntropyEngine(ent, h, w, n, "cuda:0")
     assert torch.equal(one.decode(streams), sym)
+
+
+def test_engine_knobs_that_must_not_change_a_stream(hip_backend, monkeypatch):
+    """PCONV_ENGINE_ROWS (16-byte packed CDF rows or int32[9] rows + labels across PCIe), the order of the tail
+    encode's step ranges (interleaved over the groups or group by group) and their number, the step-by-step
+    debugging encoder: the same streams, and every decoder configuration returns the coded symbols."""
+    from pseudocylindrical_convolution_amd.engine import EntropyEngine
+    enc, _ = _codec()
+    ent = enc.ent
+    h, w, n = 4, 128, 3
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(29)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    for name in ("PCONV_ENGINE_ROWS", "PCONV_ENGINE_ENCODE_INTERLEAVE", "PCONV_ENGINE_ENCODE_RANGES",
+                 "PCONV_ENGINE_STEPWISE_ENCODER", "PCONV_ENGINE_CHAIN"):
+        monkeypatch.delenv(name, raising=False)
+    ref_engine = EntropyEngine(ent, h, w, n, "cuda:0")
+    ref = ref_engine.encode(sym)
+    for env in ({"PCONV_ENGINE_ROWS": "int32"}, {"PCONV_ENGINE_ENCODE_INTERLEAVE": "0"},
+                {"PCONV_ENGINE_ENCODE_RANGES": "1"}, {"PCONV_ENGINE_ENCODE_RANGES": "7"},
+                {"PCONV_ENGINE_ROWS": "int32", "PCONV_ENGINE_CHAIN": "host"}, {"PCONV_ENGINE_CHAIN": "queued"},
+                {"PCONV_ENGINE_STEPWISE_ENCODER": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = EntropyEngine(ent, h, w, n, "cuda:0")
+        assert e.encode(sym) == ref, env
+        assert torch.equal(e.decode(ref), sym), env
+        for k in env:
+            monkeypatch.delenv(k)
+    # the per-engine setter wins over the environment and is reset by a plain encode()
+    ref_engine.encode_begin(sym, ranges=5)
+    assert ref_engine.encode_end() == ref
