@@ -93,6 +93,13 @@ int ee_conv_bulk_mfma(const EeGeom *g, const void *blocks, int nblocks, int rp_n
                       int shared_input, const float *wfrag, const float *bias, const float *slope,
                       const float *residual, float *y, int cin, int cout, int pad_out, int s_lo, int s_hi,
                       void *stream);
+// the same 42 -> 42 layer, four lane classes per instruction (v_mfma_f32_16x16x1_4b_f32), nt = 1 block shapes only
+int ee_mfma4_packed_floats(int nset, int cin);
+int ee_pack_weight_mfma4(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
+                         void *stream);
+int ee_conv_bulk_mfma4(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, const float *x,
+                       const float *wfrag4, const float *bias, const float *slope, const float *residual, float *y,
+                       int cin, int cout, int pad_out, int s_lo, int s_hi, void *stream);
 // CDF rows and labels of the symbols of those steps, written in stream order
 // packed != 0 (8 symbols, total 65536 only): `table` receives the coder's 16-byte rows (uint16 c1 .. c7 + label, see
 // include/pconv_coder.h pconv_coder_encodes_rows16), `labels` is not written

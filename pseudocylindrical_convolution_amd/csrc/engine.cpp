@@ -316,6 +316,7 @@ struct pconv_entropy_engine {
   // matrix-core form of the encoder's hidden layers (entropy_mfma.hip): weights as MFMA fragments, the list of
   // position blocks; mfma_waves == 0: not available for this shape (the vector kernel takes every layer)
   float *lwf[kLayers] = {nullptr};
+  float *lwf4[kLayers] = {nullptr};  // PCONV_EE_MFMA_FORM=4b: fragments of the four-block form (42 -> 42 layers)
   void *mfma_blocks_d = nullptr;
   int mfma_nblocks = 0, mfma_rp = 0, mfma_ct = 0, mfma_waves = 0, mfma_nt = 0;
   std::vector<int32_t> mfma_blocks_h;  // (tile, first row, first column, 0) per block
@@ -540,8 +541,15 @@ struct pconv_entropy_engine {
           const char *env0 = getenv("PCONV_EE_BULK0");
           const char *wsrc = getenv("PCONV_EE_MFMA_WSRC");
           const bool layer0 = nt == 1 && !(wsrc && wsrc[0] == 'r') && !(env0 && env0[0] == 'v');
+          // the hidden layers: four lane classes per instruction (one row per wave, weights fetched directly) unless
+          // PCONV_EE_MFMA_FORM=16x4 asks for the 16 x 16 x 4 form (round-5 A/B: profiles/round5_entropy_mfma_variants.txt)
+          const char *form = getenv("PCONV_EE_MFMA_FORM");
+          const bool four = nt == 1 && !(wsrc && wsrc[0] == 'r') && !(form && form[0] == '1');
           for (int l = layer0 ? 0 : 1; l < kLayers; l++)
-            HIP_TRY(hipMalloc(&lwf[l], (size_t)ee_mfma_packed_floats(3, layer_cin(l)) * 4));
+            if (l == 0 || !four) HIP_TRY(hipMalloc(&lwf[l], (size_t)ee_mfma_packed_floats(3, layer_cin(l)) * 4));
+          if (four)
+            for (int l = 1; l < kLayers; l++)
+              HIP_TRY(hipMalloc(&lwf4[l], (size_t)ee_mfma4_packed_floats(3, layer_cin(l)) * 4));
           mfma_nblocks = (int)(blk.size() / 4);
           mfma_rp = rp, mfma_ct = ct, mfma_waves = wv, mfma_nt = nt;
         }
@@ -572,6 +580,7 @@ struct pconv_entropy_engine {
     freed(pos_plane_d); freed(pos_d); freed(halo_d); freed(tap_in_d); freed(tap_hid_d);
     for (int l = 0; l < kLayers; l++) freed(lw[l]);
     for (int l = 0; l < kLayers; l++) freed(lwf[l]);
+    for (int l = 0; l < kLayers; l++) freed(lwf4[l]);
     freed(mfma_blocks_d);
     for (auto &kv : mfma_range_blocks) freed(kv.second.first);
     for (Group &g : groups) {
@@ -699,8 +708,11 @@ struct pconv_entropy_engine {
     for (int l = 0; l < kLayers; l++) {
       const float *in = (l == 0) ? g.ctx : g.act[l - 1];
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
-      if (mfma_waves && lwf[l] && nblist == 0) continue;  // (no block of this range: nothing to evaluate)
-      if (mfma_waves && lwf[l])
+      if (mfma_waves && (lwf[l] || lwf4[l]) && nblist == 0) continue;  // (no block of this range: nothing to evaluate)
+      if (mfma_waves && lwf4[l])
+        PC_TRY(ee_conv_bulk_mfma4(&g.geom, blist, nblist, mfma_rp, mfma_ct, mfma_waves, in, lwf4[l], lb[l], la[l], res,
+                                  g.act[l], layer_cin(l), hid, l == kLayers - 1 ? 0 : kPad, s_lo, s_hi, g.stream));
+      else if (mfma_waves && lwf[l])
         PC_TRY(ee_conv_bulk_mfma(&g.geom, blist, nblist, mfma_rp, mfma_ct, mfma_waves, mfma_nt, in, l == 0, lwf[l], lb[l],
                                  la[l], res, g.act[l], layer_cin(l), hid, l == kLayers - 1 ? 0 : kPad, s_lo, s_hi,
                                  g.stream));
@@ -912,6 +924,8 @@ int pconv_ee_set_layer(pconv_entropy_engine *e, int layer, const float *weight, 
   if (e->lwf[layer])
     PC_TRY(ee_pack_weight_mfma(weight, e->lwf[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, layer == 0 ? 5 : 6,
                                stream));
+  if (e->lwf4[layer])
+    PC_TRY(ee_pack_weight_mfma4(weight, e->lwf4[layer], 3, 3 * e->ngroup, e->layer_cin(layer), e->ngroup, 6, stream));
   e->lb[layer] = bias;
   e->la[layer] = slope;
   e->bound[layer] = true;

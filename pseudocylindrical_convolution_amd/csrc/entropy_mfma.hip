@@ -377,6 +377,309 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   }
 }
 
+
+// ---- four lane classes per instruction: v_mfma_f32_16x16x1_4b_f32 -------------------------------------------
+//
+// Four independent 16 x 16 x 1 blocks per instruction (tools/mfma16x1_4b_probe.hip: every block an exact fmaf
+// step, 32 cycles like the 16 x 16 x 4 form): block b carries lane class l0 + {0, 32, 16, 48}[b], the K = 17 chain of
+// a class is 17 instructions -- no padding to 20 -- and the first two levels of the butterfly,
+// (C_l0 + C_l0+32) + (C_l0+16 + C_l0+48), are sums of a lane's own four result blocks.  The sixteen groups l0 are
+// visited in bit-reversed order (group index 4 a + b -> l0 = 4 bitrev2(b) + bitrev2(a)), the levels xor 8, 4, 2, 1
+// are a stack of four.  Operands: lane L = block L >> 4, row / column L & 15: A = W[out 16 mt + (L & 15)][kk],
+// B = X[pos L & 15][kk], kk = l0 + dcls(L >> 4) + 64 j for step j.  A group's 51 fragments are 13 16-byte pieces
+// per lane (ee_pack_weight_mfma4), fetched straight from global memory: the piece of the NEXT group replaces a
+// piece as soon as its last step has issued, likewise the patch entry of step j -- one whole group (1 632 matrix
+// cycles) of distance without a second register set.
+constexpr int kDcls[4] = {0, 32, 16, 48};
+__host__ __device__ constexpr int bitrev2(int v) { return ((v & 1) << 1) | ((v >> 1) & 1); }
+__host__ __device__ constexpr int slots4_of(int cin) { return iter_of(cin) * kMT; }           // 51
+__host__ __device__ constexpr int quads4_of(int cin) { return (slots4_of(cin) + 3) / 4; }     // 13
+__host__ __device__ constexpr int frag4_floats(int cin) { return quads4_of(cin) * kWave * 4; }
+
+// weights (nset, cout, cin, 5, 5) -> [set][group order index i4][quad][lane][4]: slot 4 q + e = 3 j + mt
+__global__ void pack_weight_mfma4_kernel(const float *__restrict__ w, float *__restrict__ packed, int cin, int cout,
+                                         int ngroup, int slack, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int quads = quads4_of(cin), red = cin * KK;
+  const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  long long r = i >> 8;
+  const int quad = (int)(r % quads);
+  r /= quads;
+  const int i4 = (int)(r & 15), set = (int)(r >> 4);
+  const int slot = quad * 4 + e;
+  float v = 0.f;
+  if (slot < slots4_of(cin)) {
+    const int j = slot / kMT, mt = slot - j * kMT;
+    const int l0 = 4 * bitrev2(i4 & 3) + bitrev2(i4 >> 2);
+    const int kk = l0 + kDcls[lane >> 4] + kWave * j;
+    const int out = 16 * mt + (lane & 15);
+    if (kk < red && out < cout) {
+      const int tc = out / GO, o = out - tc * GO, group_in = cin / ngroup;
+      const int tap = kk / cin, ci = kk - tap * cin;
+      const int kh = tap / K5, kw = tap - kh * K5;
+      const bool ok = (2 * HALF - kh - kw) * group_in - ci + (tc + slack) * group_in > 0;
+      if (ok) v = w[(((size_t)set * ngroup + tc) * GO + o) * red + ci * KK + tap];
+    }
+  }
+  packed[i] = v;
+}
+
+#ifndef PCONV_EE4_ABL
+#define PCONV_EE4_ABL 0
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef PCONV_EE4_STAMP
+__device__ long long ee4_stamp[5 * 8192];
+#define EE4_STAMP(k)                                                                                      \
+  do {                                                                                                    \
+    const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                              \
+    if (threadIdx.x == 0 && wg_ < 8192) ee4_stamp[5 * wg_ + (k)] = wall_clock64();                         \
+  } while (0)
+#else
+#define EE4_STAMP(k)
+#endif
+
+template <int CIN, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
+    EeGeom g, const int4 *__restrict__ blocks, int rp_n, int ct_n, const float *__restrict__ x, int shared_input,
+    const float *__restrict__ wfrag, const float *__restrict__ bias, const float *__restrict__ slope,
+    const float *__restrict__ residual, float *__restrict__ y, int pad_out, int s_lo, int s_hi) {
+  constexpr int ITER = iter_of(CIN), QUADS = quads4_of(CIN), FRAG = frag4_floats(CIN);
+  constexpr int COUT = 3 * (CIN == 14 ? 14 : CIN / 3);
+  static_assert(COUT <= 16 * kMT && ITER <= 20 && K5 * CIN > 16, "shape");
+  EE4_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *patch = smem;
+  typedef const __attribute__((address_space(4))) int32_t const_i32_t;
+  const_i32_t *brec = (const_i32_t *)(blocks + blockIdx.x);
+  const int tile = brec[0], row0 = brec[1], col0 = brec[2];
+  const int pn = blockIdx.y;
+  const int set = pn / g.nimg;
+  const int h = g.h, w = g.w;
+  const int BR = rp_n, BC = 16 * ct_n, PW = BC + 4, PR = BR + 4;
+  const int width = ((const_i32_t *)g.widths)[tile];
+  {
+    const int cmax = (col0 + BC < width ? col0 + BC : width) - 1;
+    const int pmin = tile * h + row0 + col0, pmax = tile * h + row0 + BR - 1 + cmax;
+    if (pmax + g.ngroup - 1 < s_lo || pmin >= s_hi) return;
+  }
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  {
+    // the patch by LDS-DMA (see ee_conv_bulk_mfma_kernel)
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+    const int xi = shared_input ? pn % g.nimg : pn;
+    const size_t tile_elems = (size_t)(h + 2 * PAD) * (w + 2 * PAD) * CIN;
+    const float *xt = x + ((size_t)xi * g.npart + tile) * tile_elems + ((size_t)row0 * (w + 2 * PAD) + col0) * CIN;
+    const int row16 = PW * CIN / 4;
+    const int lim16 = (w + 2 * PAD - col0) * CIN / 4;
+    const int npiece = PR * row16;
+    const size_t buf_pitch = (size_t)(w + 2 * PAD) * CIN;
+    int pr = tid / row16, j = tid - pr * row16;
+    const int dpr = (WAVES * kWave) / row16, dj = (WAVES * kWave) - dpr * row16;
+    for (int p0 = 0; p0 < npiece; p0 += WAVES * kWave) {
+      const bool in = p0 + tid < npiece;
+      const int prc = in ? pr : PR - 1, jc = in ? j : row16 - 1;
+      const float *src = xt + prc * buf_pitch + 4 * (jc < lim16 ? jc : lim16 - 1);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)src, (lds_ptr_t *)(patch + (size_t)(p0 + wave * kWave) * 4), 16, 0, 0);
+      pr += dpr;
+      j += dj;
+      if (j >= row16) {
+        j -= row16;
+        pr++;
+      }
+    }
+    const int rounded = (npiece + WAVES * kWave - 1) / (WAVES * kWave) * (WAVES * kWave) * 4;
+    for (int k = tid; k < kPatchSlack; k += WAVES * kWave) patch[rounded + k] = 0.f;
+  }
+  const int rp = wave % rp_n, ct = wave / rp_n;
+  const int q = lane >> 4;  // block of the operands = lane class of the group; row quad of the results
+  const bool live = col0 + 16 * ct < width;
+  // the first group's weight pieces and the residual of this wave's outputs travel with the patch
+  const float *wset = wfrag + (size_t)set * 16 * FRAG;
+  float4 aq[QUADS];
+  auto load_a = [&](int i4, int qd) { aq[qd] = *(reinterpret_cast<const float4 *>(wset + (size_t)i4 * FRAG) + qd * kWave + lane); };
+#pragma unroll
+  for (int qd = 0; qd < QUADS; qd++) load_a(0, qd);
+  // way out: lane L holds outputs 16 mt + 4 (L >> 4) + r of position (row rp, column L & 15)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int row = row0 + rp, col = col0 + 16 * ct + (lane & 15);
+  const int colc = col < width ? col : width - 1;  // (lanes past the tile's width: a live address, nothing stored)
+  const size_t ob0 = ((((size_t)pn * g.npart + tile) * (h + 2 * pad_out) + row + pad_out) * (w + 2 * pad_out) + colc + pad_out) * COUT;
+  f2 r01[kMT], r23[kMT];
+#pragma unroll
+  for (int mt = 0; mt < kMT; mt++) {
+    r01[mt] = r23[mt] = (f2){0.f, 0.f};
+    if (residual) {
+      const int out0 = 16 * mt + 4 * q;
+      r01[mt] = *reinterpret_cast<const f2 *>(residual + ob0 + (out0 < COUT ? out0 : COUT - 2));
+      r23[mt] = *reinterpret_cast<const f2 *>(residual + ob0 + (out0 + 2 < COUT ? out0 + 2 : COUT - 2));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the patch DMA of every wave
+  EE4_STAMP(1);
+  if (!live) return;                                                         // (no barrier from here on)
+  const int dcls = q == 0 ? kDcls[0] : (q == 1 ? kDcls[1] : (q == 2 ? kDcls[2] : kDcls[3]));
+  const int kh_stride = (PW - K5) * CIN;
+  // byte offset of entry kk = l0 + dcls + 64 j of this lane's window: 4 (lane_base + kk + kh kh_stride), kh = the
+  // window row of entry dcls + 64 j (compile-time per block: packed three bits per step), one row further from
+  // l0 = thr on in the ONE step of this block whose sixteen classes straddle a row end (5 CIN = 210 entries)
+  const unsigned base_b = 4u * (unsigned)(((rp)*PW + 16 * ct + (lane & 15)) * CIN + dcls);
+  unsigned long long khpack = 0;
+  int jspec = -1, thr = 99;
+#pragma unroll
+  for (int j = 0; j < ITER; j++) {
+    const int c = dcls + kWave * j;
+    int kh0 = c / (K5 * CIN);
+    kh0 = kh0 < K5 - 1 ? kh0 : K5 - 1;
+    khpack |= (unsigned long long)kh0 << (3 * j);
+    const int cross = (kh0 + 1) * K5 * CIN - c;
+    if (kh0 < K5 - 1 && cross < 16) jspec = j, thr = cross;
+  }
+  float bj[ITER];
+  auto load_b = [&](int l0, int j) {
+    int kh = (int)((khpack >> (3 * j)) & 7u);
+    if (j == jspec && l0 >= thr) kh++;
+    const unsigned off = base_b + 4u * (unsigned)(kWave * j + l0) + 4u * (unsigned)(kh * kh_stride);
+    bj[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(patch) + off);
+  };
+#pragma unroll
+  for (int j = 0; j < ITER; j++) load_b(0, j);
+
+  f32x4 T1[kMT], T2[kMT], T3[kMT], T4[kMT], tot[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; t++) T1[t] = T2[t] = T3[t] = T4[t] = tot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if PCONV_EE4_ABL & 8
+  f32x16 acc[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+#endif
+#pragma unroll 1
+  for (int a = 0; a < ((PCONV_EE4_ABL & 1) ? (int)(s_lo > 12345678) : 4); a++) {
+    f32x4 Q[kMT];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int i4 = 4 * a + b;
+      // the next group (behind the last one: a dummy, group 15 again)
+      const int n4 = i4 + 1 < 16 ? i4 + 1 : 15;
+      const int ln = b < 3 ? 4 * bitrev2(b + 1) + bitrev2(a) : (a < 3 ? bitrev2(a + 1) : 4 * bitrev2(3) + bitrev2(3));
+#if !(PCONV_EE4_ABL & 8)
+      f32x16 acc[kMT];
+#pragma unroll
+      for (int t = 0; t < kMT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+#endif
+#pragma unroll
+      for (int j = 0; j < ITER; j++) {
+#pragma unroll
+        for (int mt = 0; mt < kMT; mt++) {
+          const int s = j * kMT + mt;
+          const float av = s % 4 == 0 ? aq[s / 4].x : (s % 4 == 1 ? aq[s / 4].y : (s % 4 == 2 ? aq[s / 4].z : aq[s / 4].w));
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bj[j], acc[mt], 0, 0, 0);
+          if (s % 4 == 3 || s == ITER * kMT - 1) {  // (this piece's last step has issued)
+#if !(PCONV_EE4_ABL & 2)
+            load_a(n4, s / 4);
+#else
+            asm volatile("" : "+v"(aq[s / 4].x), "+v"(aq[s / 4].y), "+v"(aq[s / 4].z), "+v"(aq[s / 4].w));
+#endif
+            __builtin_amdgcn_sched_barrier(0);  // here, not where the scheduler would cluster the fetches: a piece is
+          }                                     // waited for by count, in the order of its use
+        }
+#if !(PCONV_EE4_ABL & 4)
+        load_b(ln, j);
+#else
+        asm volatile("" : "+v"(bj[j]));
+#endif
+      }
+      // the butterfly: xor 32 and xor 16 inside the lane, then the stack over the group index
+#if PCONV_EE4_ABL & 8
+      if (a == 3 && b == 3)
+#endif
+#pragma unroll
+      for (int t = 0; t < kMT; t++) {
+        f32x4 s2;
+#pragma unroll
+        for (int r = 0; r < 4; r++) s2[r] = (acc[t][r] + acc[t][4 + r]) + (acc[t][8 + r] + acc[t][12 + r]);
+        if ((b & 1) == 0) {
+          T1[t] = s2;
+        } else {
+          const f32x4 u = T1[t] + s2;  // xor 8
+          if ((b & 2) == 0)
+            T2[t] = u;
+          else
+            Q[t] = T2[t] + u;  // xor 4
+        }
+      }
+    }
+    // xor 2, xor 1 over the outer index: selects, not branches (one basic block per turn of the loop -- behind
+    // branches the wait-count pass drains every fetch at the loop's head); only the last turn's `tot` is used
+    const bool even = (a & 1) == 0, second = a == 1;
+#pragma unroll
+    for (int t = 0; t < kMT; t++) {
+      const f32x4 u = T3[t] + Q[t];
+      tot[t] = T4[t] + u;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        T3[t][r] = even ? Q[t][r] : T3[t][r];
+        T4[t][r] = second ? u[r] : T4[t][r];
+      }
+    }
+  }
+  // way out (bias, slope, the residual fetched in the prologue), 8-byte stores
+  EE4_STAMP(2);
+#ifdef PCONV_EE4_STAMP
+  if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 8192) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ee4_stamp[5 * (blockIdx.x + gridDim.x * blockIdx.y) + 4] = ((long long)xcc << 32) | hw;
+  }
+#endif
+  if (col >= width) return;
+  const bool whole = s_lo <= 0 && s_hi > g.h * g.npart + g.w + g.ngroup;
+  const float *bset = bias + set * COUT, *sset = slope ? slope + set * COUT : nullptr;
+  const int plane = tile * h + row + col;
+#pragma unroll
+  for (int mt = 0; mt < kMT; mt++) {
+    const int out0 = 16 * mt + 4 * q;
+    if (out0 >= COUT) continue;
+    const bool second = out0 + 2 < COUT;
+    const f2 b01 = *reinterpret_cast<const f2 *>(bset + out0);
+    const f2 b23 = second ? *reinterpret_cast<const f2 *>(bset + out0 + 2) : (f2){0.f, 0.f};
+    f2 s01 = {1.f, 1.f}, s23 = {1.f, 1.f};
+    if (sset) {
+      s01 = *reinterpret_cast<const f2 *>(sset + out0);
+      if (second) s23 = *reinterpret_cast<const f2 *>(sset + out0 + 2);
+    }
+    const size_t ob = ob0 + out0;
+    const f32x4 t = tot[mt];
+    float v[4] = {t[0] + b01[0], t[1] + b01[1], t[2] + b23[0], t[3] + b23[1]};
+    const float sl[4] = {s01[0], s01[1], s23[0], s23[1]}, rs[4] = {r01[mt][0], r01[mt][1], r23[mt][0], r23[mt][1]};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (v[r] < 0) v[r] = v[r] * sl[r];
+      if (residual) v[r] = v[r] + rs[r];
+    }
+    if (whole) {
+      *reinterpret_cast<f2 *>(y + ob) = (f2){v[0], v[1]};
+      if (second) *reinterpret_cast<f2 *>(y + ob + 2) = (f2){v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int step = plane + (out0 + r) / GO;
+        if (out0 + r < COUT && step >= s_lo && step < s_hi) y[ob + r] = v[r];
+      }
+    }
+  }
+  EE4_STAMP(3);
+}
+
 }  // namespace
 
 int ee_mfma_packed_floats(int nset, int cin) { return nset * 64 * frag_floats(cin); }
@@ -394,6 +697,63 @@ int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int c
 
 // a block is nt * rp_n rows x 16 ct_n columns, rp_n * ct_n = waves of a workgroup, nt = rows of a wave (1 or 2;
 // PCONV_EE_MFMA_NT); rows per tile must be a multiple of nt * rp_n
+#ifdef PCONV_EE4_STAMP
+extern "C" int pconv_debug_ee4_stamps(long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ee4_stamp), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+int ee_mfma4_packed_floats(int nset, int cin) { return nset * 16 * frag4_floats(cin); }
+
+int ee_pack_weight_mfma4(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
+                         void *stream) {
+  PCONV_REQUIRE(cout == GO * ngroup && cin % ngroup == 0 && (constrain == 5 || constrain == 6) && cout <= 16 * kMT,
+                "ee_pack_weight_mfma4: bad layer shape");
+  const long long total = (long long)ee_mfma4_packed_floats(nset, cin);
+  hipLaunchKernelGGL(pack_weight_mfma4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w,
+                     packed, cin, cout, ngroup, constrain == 5 ? 0 : 1, total);
+  PCONV_LAUNCH_CHECK("ee_pack_weight_mfma4");
+  return PCONV_OK;
+}
+
+// the four-classes-per-instruction form (42 channels, one row per wave)
+int ee_conv_bulk_mfma4(const EeGeom *g, const void *blocks, int nblocks, int rp_n, int ct_n, int waves, const float *x,
+                       const float *wfrag4, const float *bias, const float *slope, const float *residual, float *y,
+                       int cin, int cout, int pad_out, int s_lo, int s_hi, void *stream) {
+  PCONV_REQUIRE(cin == 42 && cout == 42 && g->ngroup == 14, "ee_conv_bulk_mfma4: 42 -> 42 channels only");
+  PCONV_REQUIRE(rp_n > 0 && ct_n > 0 && rp_n * ct_n == waves && (waves == 4 || waves == 8) && g->h % rp_n == 0,
+                "ee_conv_bulk_mfma4: bad block shape");
+  PCONV_REQUIRE(s_lo < s_hi && nblocks > 0, "ee_conv_bulk_mfma4: bad range");
+  const size_t round = (size_t)waves * kWave * 16;
+  const size_t patch_bytes = ((size_t)(rp_n + 4) * (16 * ct_n + 4) * cin * sizeof(float) + round - 1) / round * round;
+  const size_t smem = patch_bytes + kPatchSlack * sizeof(float);
+  PCONV_REQUIRE(smem <= 160 * 1024, "ee_conv_bulk_mfma4: block needs %zu bytes of LDS", smem);
+  const dim3 grid((unsigned)nblocks, (unsigned)(3 * g->nimg));
+  PCONV_REQUIRE(grid.y <= 65535u, "ee_conv_bulk_mfma4: too many images for one launch");
+  typedef void (*kernel_t)(EeGeom, const int4 *, int, int, const float *, int, const float *, const float *, const float *,
+                           const float *, float *, int, int, int);
+  static const kernel_t kernels[2] = {ee_conv_bulk_mfma4_kernel<42, 4>, ee_conv_bulk_mfma4_kernel<42, 8>};
+  const int kind = waves == 8;
+  {
+    static std::atomic<unsigned long long> raised[2];
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+    const unsigned long long bit = 1ULL << (device & 63);
+    if (!(raised[kind].load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernels[kind]),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        pconv_set_error("ee_conv_bulk_mfma4: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+        return PCONV_ELAUNCH;
+      }
+      raised[kind].fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL(kernels[kind], grid, dim3(waves * kWave), smem, as_stream(stream), *g, (const int4 *)blocks, rp_n, ct_n, x,
+                     0, wfrag4, bias, slope, residual, y, pad_out, s_lo, s_hi);
+  PCONV_LAUNCH_CHECK("ee_conv_bulk_mfma4");
+  return PCONV_OK;
+}
+
 // PCONV_EE_MFMA_WSRC=ring: the LDS-ring form of the one-row kernel (default: direct fetch)
 static bool mfma_direct(int nt) {
   const bool ring = getenv("PCONV_EE_MFMA_WSRC") && getenv("PCONV_EE_MFMA_WSRC")[0] == 'r';  // (per call: tests switch it)

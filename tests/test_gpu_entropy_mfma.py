@@ -76,7 +76,24 @@ def test_measured_variants_of_the_matrix_core_kernel_agree(hip_backend, monkeypa
     sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(17)).float().cuda()
     sym = ent.fill(sym).contiguous()
     ref = _encode(ent, sym, h, w, n, "valu", monkeypatch, ranges=2)
+    monkeypatch.setenv("PCONV_EE_MFMA_FORM", "16x4")
     monkeypatch.setenv("PCONV_EE_MFMA_NT", str(nt))
     monkeypatch.setenv("PCONV_EE_MFMA_WAVES", str(waves))
     monkeypatch.setenv("PCONV_EE_MFMA_WSRC", wsrc)
     assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=2) == ref
+
+
+@pytest.mark.parametrize("h,w,n,waves,ranges", [(8, 192, 1, 4, 2), (16, 512, 1, 4, 1), (3, 64, 1, 4, 1), (2, 80, 3, 4, 3),
+                                                (8, 256, 2, 8, 1)])
+def test_four_block_form_of_the_matrix_core_kernel_agrees(hip_backend, monkeypatch, h, w, n, waves, ranges):
+    """four lane classes per instruction (v_mfma_f32_16x16x1_4b_f32, the default form of the hidden layers; the
+    16 x 16 x 4 form is PCONV_EE_MFMA_FORM=16x4), the first two butterfly levels inside a lane: the same streams"""
+    ent = _ent(19)
+    sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(23 + h)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    ref = _encode(ent, sym, h, w, n, "valu", monkeypatch, ranges=ranges)
+    monkeypatch.setenv("PCONV_EE_MFMA_WAVES", str(waves))
+    monkeypatch.setenv("PCONV_EE_MFMA_FORM", "4b")
+    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=ranges) == ref
+    monkeypatch.setenv("PCONV_EE_MFMA_FORM", "16x4")
+    assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=ranges) == ref

@@ -18,8 +18,9 @@ enc.ent.load_state_dict(sd)
 sym = torch.randint(0, 8, (16 * N, 14, H, W), generator=torch.Generator().manual_seed(3)).float().cuda()
 sym = enc.ent.fill(sym).contiguous()
 res = {}
-for mode in ("valu", "mfma"):
-    os.environ["PCONV_EE_BULK"] = mode
+for mode in ("valu", "mfma", "mfma4"):
+    os.environ["PCONV_EE_BULK"] = mode[:4]
+    os.environ["PCONV_EE_MFMA_FORM"] = "4b" if mode == "mfma4" else "16x4"
     e = EntropyEngine(enc.ent, H, W, N, "cuda:0")
     best = 1e9
     for rep in range(reps):
@@ -28,6 +29,6 @@ for mode in ("valu", "mfma"):
         best = min(best, t1 - t0)
     res[mode] = (streams, best)
     print("N=%d %dx%d %s: entropy encode %.4f s, bytes %d" % (N, H, W, mode, best, len(streams[0])), flush=True)
-same = res["valu"][0] == res["mfma"][0]
+same = res["valu"][0] == res["mfma"][0] == res["mfma4"][0]
 print("streams identical:", same, flush=True)
 sys.exit(0 if same else 1)
