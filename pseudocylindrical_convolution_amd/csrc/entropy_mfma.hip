@@ -425,20 +425,7 @@ __global__ void pack_weight_mfma4_kernel(const float *__restrict__ w, float *__r
   packed[i] = v;
 }
 
-#ifndef PCONV_EE4_ABL
-#define PCONV_EE4_ABL 0
-#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifdef PCONV_EE4_STAMP
-__device__ long long ee4_stamp[5 * 8192];
-#define EE4_STAMP(k)                                                                                      \
-  do {                                                                                                    \
-    const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                              \
-    if (threadIdx.x == 0 && wg_ < 8192) ee4_stamp[5 * wg_ + (k)] = wall_clock64();                         \
-  } while (0)
-#else
-#define EE4_STAMP(k)
-#endif
 
 template <int CIN, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
@@ -448,7 +435,6 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
   constexpr int ITER = iter_of(CIN), QUADS = quads4_of(CIN), FRAG = frag4_floats(CIN);
   constexpr int COUT = 3 * (CIN == 14 ? 14 : CIN / 3);
   static_assert(COUT <= 16 * kMT && ITER <= 20 && K5 * CIN > 16, "shape");
-  EE4_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *patch = smem;
   typedef const __attribute__((address_space(4))) int32_t const_i32_t;
@@ -519,7 +505,6 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the patch DMA of every wave
-  EE4_STAMP(1);
   if (!live) return;                                                         // (no barrier from here on)
   const int dcls = q == 0 ? kDcls[0] : (q == 1 ? kDcls[1] : (q == 2 ? kDcls[2] : kDcls[3]));
   const int kh_stride = (PW - K5) * CIN;
@@ -551,15 +536,8 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
   f32x4 T1[kMT], T2[kMT], T3[kMT], T4[kMT], tot[kMT];
 #pragma unroll
   for (int t = 0; t < kMT; t++) T1[t] = T2[t] = T3[t] = T4[t] = tot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if PCONV_EE4_ABL & 8
-  f32x16 acc[kMT];
-#pragma unroll
-  for (int t = 0; t < kMT; t++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-#endif
 #pragma unroll 1
-  for (int a = 0; a < ((PCONV_EE4_ABL & 1) ? (int)(s_lo > 12345678) : 4); a++) {
+  for (int a = 0; a < 4; a++) {
     f32x4 Q[kMT];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -567,13 +545,11 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
       // the next group (behind the last one: a dummy, group 15 again)
       const int n4 = i4 + 1 < 16 ? i4 + 1 : 15;
       const int ln = b < 3 ? 4 * bitrev2(b + 1) + bitrev2(a) : (a < 3 ? bitrev2(a + 1) : 4 * bitrev2(3) + bitrev2(3));
-#if !(PCONV_EE4_ABL & 8)
       f32x16 acc[kMT];
 #pragma unroll
       for (int t = 0; t < kMT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-#endif
 #pragma unroll
       for (int j = 0; j < ITER; j++) {
 #pragma unroll
@@ -582,24 +558,13 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
           const float av = s % 4 == 0 ? aq[s / 4].x : (s % 4 == 1 ? aq[s / 4].y : (s % 4 == 2 ? aq[s / 4].z : aq[s / 4].w));
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bj[j], acc[mt], 0, 0, 0);
           if (s % 4 == 3 || s == ITER * kMT - 1) {  // (this piece's last step has issued)
-#if !(PCONV_EE4_ABL & 2)
             load_a(n4, s / 4);
-#else
-            asm volatile("" : "+v"(aq[s / 4].x), "+v"(aq[s / 4].y), "+v"(aq[s / 4].z), "+v"(aq[s / 4].w));
-#endif
             __builtin_amdgcn_sched_barrier(0);  // here, not where the scheduler would cluster the fetches: a piece is
           }                                     // waited for by count, in the order of its use
         }
-#if !(PCONV_EE4_ABL & 4)
         load_b(ln, j);
-#else
-        asm volatile("" : "+v"(bj[j]));
-#endif
       }
       // the butterfly: xor 32 and xor 16 inside the lane, then the stack over the group index
-#if PCONV_EE4_ABL & 8
-      if (a == 3 && b == 3)
-#endif
 #pragma unroll
       for (int t = 0; t < kMT; t++) {
         f32x4 s2;
@@ -631,16 +596,6 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
     }
   }
   // way out (bias, slope, the residual fetched in the prologue), 8-byte stores
-  EE4_STAMP(2);
-#ifdef PCONV_EE4_STAMP
-  if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 8192) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    ee4_stamp[5 * (blockIdx.x + gridDim.x * blockIdx.y) + 4] = ((long long)xcc << 32) | hw;
-  }
-#endif
   if (col >= width) return;
   const bool whole = s_lo <= 0 && s_hi > g.h * g.npart + g.w + g.ngroup;
   const float *bset = bias + set * COUT, *sset = slope ? slope + set * COUT : nullptr;
@@ -677,7 +632,6 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
       }
     }
   }
-  EE4_STAMP(3);
 }
 
 }  // namespace
@@ -697,11 +651,6 @@ int ee_pack_weight_mfma(const float *w, float *packed, int nset, int cout, int c
 
 // a block is nt * rp_n rows x 16 ct_n columns, rp_n * ct_n = waves of a workgroup, nt = rows of a wave (1 or 2;
 // PCONV_EE_MFMA_NT); rows per tile must be a multiple of nt * rp_n
-#ifdef PCONV_EE4_STAMP
-extern "C" int pconv_debug_ee4_stamps(long long *host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ee4_stamp), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
-}
-#endif
 int ee_mfma4_packed_floats(int nset, int cin) { return nset * 16 * frag4_floats(cin); }
 
 int ee_pack_weight_mfma4(const float *w, float *packed, int nset, int cout, int cin, int ngroup, int constrain,
