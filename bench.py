@@ -344,6 +344,22 @@ def cpu_baseline(sample_h, sample_w):
                         "entropy_decode": round(t3 - t2, 2), "synthesis": round(t4 - t3, 2)}}
 
 
+def cu_masked_stream(spec, device):
+    """PCONV_BENCH_CU_MASK=first:count -- a stream whose kernels run on `count` compute units from bit `first` of
+    the CU mask on (experiments: the transforms on one partition of the chip, the entropy chains on the other)"""
+    import ctypes
+    first, count = (int(v) for v in spec.split(":"))
+    mask = (ctypes.c_uint32 * 8)()
+    for b in range(max(first, 0), min(first + count, 256)):
+        mask[b >> 5] |= 1 << (b & 31)
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), 8, mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask: %d" % rc)
+    return torch.cuda.ExternalStream(stream.value, device=device)
+
+
 class CodecWorkload(object):
     """BASELINE config #5's per-GPU share: F frames encoded and decoded per step on the
     native engine; frames resident in HBM, streams in host memory"""
@@ -498,6 +514,8 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
     dev = "cuda:%d" % local_dev if on_gpu else "cpu"
     n_joined = dist.get_world_size() if world > 1 else 1
 
+    if on_gpu and os.environ.get("PCONV_BENCH_CU_MASK"):
+        torch.cuda.set_stream(cu_masked_stream(os.environ["PCONV_BENCH_CU_MASK"], local_dev))
     load = (workload_cls or WORKLOADS[args.mode])(args, rank, local_dev, dev)
 
     def fence():

@@ -367,7 +367,19 @@ struct pconv_entropy_engine {
     // beside a decode doubled its GPU waits, so CodecEngine does not overlap them.)
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest));
+    // PCONV_ENGINE_CU_MASK=first:count -- the group's stream on `count` compute units from bit `first` of the CU
+    // mask on (consecutive bits alternate over the XCDs and their shader engines): a partition of the chip for
+    // the chains, so that they can run beside another stream's transforms (which hold whole CUs)
+    int cu_first = 0, cu_count = 0;
+    if (const char *m = getenv("PCONV_ENGINE_CU_MASK")) (void)sscanf(m, "%d:%d", &cu_first, &cu_count);
+    if (cu_count > 0) {
+      uint32_t mask[8] = {0};
+      for (int b = cu_first; b < cu_first + cu_count && b < 256; b++)
+        if (b >= 0) mask[b >> 5] |= 1u << (b & 31);
+      HIP_TRY(hipExtStreamCreateWithCUMask(&g.stream, 8, mask));
+    } else {
+      HIP_TRY(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest));
+    }
     HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     for (int k = 0; k < kMaxEncodeRanges; k++) HIP_TRY(hipEventCreateWithFlags(&g.enc_done[k], hipEventDisableTiming));
     g.step_row.assign(nsteps + 1, 0);
