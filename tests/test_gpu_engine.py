@@ -266,7 +266,8 @@ def test_host_constrained_plan_decodes_the_same_symbols(hip_backend, monkeypatch
 def test_engine_knobs_that_must_not_change_a_stream(hip_backend, monkeypatch):
     """PCONV_ENGINE_ROWS (16-byte packed CDF rows or int32[9] rows + labels across PCIe), the order of the tail
     encode's step ranges (interleaved over the groups or group by group) and their number, the step-by-step
-    debugging encoder: the same streams, and every decoder configuration returns the coded symbols."""
+    debugging encoder, the engine's streams on a partition of the compute units, the other matrix-core form of the
+    encoder's hidden layers: the same streams, and every decoder configuration returns the coded symbols."""
     from pseudocylindrical_convolution_amd.engine import EntropyEngine
     enc, _ = _codec()
     ent = enc.ent
@@ -274,14 +275,15 @@ def test_engine_knobs_that_must_not_change_a_stream(hip_backend, monkeypatch):
     sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(29)).float().cuda()
     sym = ent.fill(sym).contiguous()
     for name in ("PCONV_ENGINE_ROWS", "PCONV_ENGINE_ENCODE_INTERLEAVE", "PCONV_ENGINE_ENCODE_RANGES",
-                 "PCONV_ENGINE_STEPWISE_ENCODER", "PCONV_ENGINE_CHAIN"):
+                 "PCONV_ENGINE_STEPWISE_ENCODER", "PCONV_ENGINE_CHAIN", "PCONV_ENGINE_CU_MASK", "PCONV_EE_MFMA_FORM"):
         monkeypatch.delenv(name, raising=False)
     ref_engine = EntropyEngine(ent, h, w, n, "cuda:0")
     ref = ref_engine.encode(sym)
     for env in ({"PCONV_ENGINE_ROWS": "int32"}, {"PCONV_ENGINE_ENCODE_INTERLEAVE": "0"},
                 {"PCONV_ENGINE_ENCODE_RANGES": "1"}, {"PCONV_ENGINE_ENCODE_RANGES": "7"},
                 {"PCONV_ENGINE_ROWS": "int32", "PCONV_ENGINE_CHAIN": "host"}, {"PCONV_ENGINE_CHAIN": "queued"},
-                {"PCONV_ENGINE_STEPWISE_ENCODER": "1"}):
+                {"PCONV_ENGINE_STEPWISE_ENCODER": "1"}, {"PCONV_ENGINE_CU_MASK": "0:64"},
+                {"PCONV_EE_MFMA_FORM": "16x4"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         e = EntropyEngine(ent, h, w, n, "cuda:0")
