@@ -438,9 +438,13 @@ int pconv_ee_spin_us(int call_threads);
  * chains = driver threads), threads that arithmetic-decode a group's frames (0 = one per frame), queued-ahead (1)
  * or host-driven (0) chain, waits that sleep instead of spinning.  With nimg + 1 <= pconv_ee_host_cpus(): the
  * measured best of profiles/round3_decode_groups.txt; otherwise (a rank with a small share of the host) at most
- * one group per CPU, one decoding thread per group, host-driven chain, sleeping waits
+ * one group per CPU, one decoding thread per group, host-driven chain, sleeping waits (blocking events)
  * (profiles/round5_host_share.txt).  PCONV_ENGINE_GROUPS / _WORKERS / _CHAIN / _BLOCKING_SYNC override. */
 int pconv_ee_host_plan(int nimg, int *groups, int *group_threads, int *queued_chain, int *blocking_sync);
+/* How the host threads of THIS engine wait for the GPU: 0 = the runtime's default (spinning) stream waits, 1 = sleeping
+ * waits on blocking events (hipEventBlockingSync; the plan's blocking_sync, fixed at pconv_ee_create).  No device-wide
+ * schedule flag is set either way. */
+int pconv_ee_wait_mode(const pconv_entropy_engine *e);
 /* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */
 int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream);
 /* the same in two halves: begin queues the GPU part IN `stream` and starts the host thread that

@@ -69,6 +69,87 @@ class SyntheticSphereDataSet(Dataset):
         return img.clamp_(0, 1).contiguous()
 
 
+class ProceduralSphereDataSet(Dataset):
+    """`count` seeded procedural ERP images for training where no photographs exist: a smooth colour
+    gradient (low-frequency waves, integer horizontal frequencies so that the frame wraps), a
+    band-limited texture (octaves of bilinearly up-sampled noise with a random fall-off), flat or
+    shaded shapes with hard edges (rectangles, ellipses, half planes, stripes) and a little sensor
+    noise.  The per-image value the balanced sampler reads is the image's detail level."""
+
+    def __init__(self, count, height=512, width=1024, seed=0):
+        self.count, self.height, self.width, self.seed = int(count), int(height), int(width), int(seed)
+        self.img_list = ['procedural_%06d.png' % i for i in range(self.count)]
+        g = torch.Generator().manual_seed(self.seed)
+        self.detail = (0.5 + 2.0 * torch.rand(self.count, generator=g)).tolist()
+
+    def values(self):
+        return {name: v for name, v in zip(self.img_list, self.detail)}
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        return procedural_erp(self.height, self.width, self.seed * 1000003 + int(idx), self.detail[int(idx)])
+
+
+def procedural_erp(height, width, seed, detail=1.5):
+    """one (3, height, width) image in [0, 1]; `detail` in [0.5, 2.5] scales texture and shape count"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(int(seed))
+    H, W = int(height), int(width)
+    yy = torch.linspace(0, 1, H).view(1, H, 1)
+    xx = torch.linspace(0, 1, W).view(1, 1, W)
+
+    def rnd(*shape):
+        return torch.rand(*shape, generator=g)
+
+    def texture(channels, octaves, falloff, coarsest):
+        t = torch.zeros(channels, H, W)
+        amp = 1.0
+        for o in range(octaves):
+            s = max(1, coarsest >> o)
+            hh, ww = max(2, H // s), max(2, W // s)
+            n = rnd(1, channels, hh, ww) - 0.5
+            n = torch.cat([n, n[..., :1]], 3)                       # the noise wraps with the frame
+            t += amp * F.interpolate(n, size=(H, W + W // ww), mode='bilinear', align_corners=False)[0, :, :, :W]
+            amp *= falloff
+        return t
+
+    # smooth gradient between two colours
+    c0, c1 = rnd(3, 1, 1), rnd(3, 1, 1)
+    mix = 0.5 * torch.ones(1, H, W)
+    for _ in range(3):
+        fy, fx = float(rnd(1)) * 3, int(rnd(1) * 3)
+        mix = mix + 0.25 * torch.cos(6.2832 * (fy * yy + fx * xx) + 6.2832 * float(rnd(1)))
+    img = c0 + (c1 - c0) * mix.clamp(0, 1)
+    # band-limited texture, coarse to fine
+    img = img + (0.10 + 0.08 * detail) * texture(3, 5, 0.35 + 0.3 * float(rnd(1)), 64)
+    # shapes with hard edges
+    for _ in range(int(2 + 3 * detail + 4 * float(rnd(1)))):
+        kind = int(rnd(1) * 4)
+        cy, cx = float(rnd(1)), float(rnd(1))
+        ry, rx = 0.02 + 0.25 * float(rnd(1)), 0.01 + 0.15 * float(rnd(1))
+        dx = (xx - cx + 0.5) % 1.0 - 0.5                             # horizontal distance on the circle
+        dy = yy - cy
+        if kind == 0:
+            m = (dx.abs() < rx) & (dy.abs() < ry)
+        elif kind == 1:
+            m = (dx / rx) ** 2 + (dy / ry) ** 2 < 1.0
+        elif kind == 2:
+            a = 6.2832 * float(rnd(1))
+            m = ((dx * np.cos(a) + dy * np.sin(a)) > 0) & (dy.abs() < ry)
+        else:
+            period = 0.01 + 0.05 * float(rnd(1))
+            m = (((dx + 2 * dy) / period).floor() % 2 == 0) & (dx.abs() < rx) & (dy.abs() < ry)
+        col = rnd(3, 1, 1)
+        shade = 1.0 + 0.3 * (rnd(1) - 0.5) * (dy / ry).clamp(-1, 1)
+        img = torch.where(m, (col * shade).expand(3, H, W), img)
+    img = img + 0.004 * detail * torch.randn(3, H, W, generator=g)
+    return img.clamp_(0, 1).contiguous()
+
+
 def balance_windows(indices, value_of, window, threshold):
     """Reorder `indices` in place so that every run of `window` consecutive entries (one optimiser
     step over all ranks and accumulation rounds) has sum(value) >= threshold

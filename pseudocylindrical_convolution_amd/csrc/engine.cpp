@@ -278,6 +278,7 @@ struct Group {
   EeGeom geom;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
+  hipEvent_t step_done = nullptr;      // decoder, sleeping waits: "this step's rows are on the host" (a blocking event)
   std::vector<int> enc_bounds;         // encoder: step ranges (set_encode_ranges, encode_range)
   hipEvent_t enc_done[8] = {nullptr};  // ... and "this range's rows are on the host"
   float *ctx = nullptr;             // (nimg*npart, h+4, w+4, G)
@@ -310,6 +311,7 @@ struct pconv_entropy_engine {
   uint32_t *tap_in_d = nullptr, *tap_hid_d = nullptr;
   float *vh_wgt = nullptr;
   int32_t *pos_plane_d = nullptr;
+  HostPlan plan;                  // the host side of this engine's calls, decided ONCE (pconv_ee_create)
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
   int encode_ranges = -1;         // step ranges of a call's last group (pconv_ee_set_encode_ranges); -1: the default
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
@@ -380,8 +382,13 @@ struct pconv_entropy_engine {
     } else {
       HIP_TRY(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest));
     }
-    HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
-    for (int k = 0; k < kMaxEncodeRanges; k++) HIP_TRY(hipEventCreateWithFlags(&g.enc_done[k], hipEventDisableTiming));
+    // sleeping waits (host-constrained rank, host_plan): the events the host threads wait on are BLOCKING events --
+    // hipEventSynchronize sleeps on the signal's interrupt instead of spinning.  A property of these events only:
+    // no device-wide schedule flag is touched (torch's own synchronisations keep their behaviour)
+    const unsigned evflags = hipEventDisableTiming | (plan.blocking_sync ? hipEventBlockingSync : 0u);
+    HIP_TRY(hipEventCreateWithFlags(&g.done, evflags));
+    HIP_TRY(hipEventCreateWithFlags(&g.step_done, evflags));
+    for (int k = 0; k < kMaxEncodeRanges; k++) HIP_TRY(hipEventCreateWithFlags(&g.enc_done[k], evflags));
     g.step_row.assign(nsteps + 1, 0);
     for (int s = 0; s < nsteps; s++) g.step_row[s + 1] = g.step_row[s] + window(s).len * n;
     HIP_TRY(hipMalloc(&g.step_row_d, g.step_row.size() * 4));
@@ -536,7 +543,10 @@ struct pconv_entropy_engine {
       // PCONV_EE_BULK=valu keeps the vector kernel for every layer of the encoder (A/B; identical streams)
       const char *env = getenv("PCONV_EE_BULK");
       int rp = 0, ct = 0, wv = 0, nt = 0;
-      if (!(env && env[0] == 'v') && ngroup == 14 && ee_mfma_block_shape(h, 3 * ngroup, &rp, &ct, &wv, &nt)) {
+      // even widths only: the patch goes to LDS in 16-byte pieces and a padded row of an odd width ends on half a
+      // piece (a pixel is 14 / 42 floats) -- the codec's symbol planes are Dtow(2) outputs, always even; direct
+      // pconv_ee_create users with an odd w get the vector kernel
+      if (!(env && env[0] == 'v') && ngroup == 14 && (w & 1) == 0 && ee_mfma_block_shape(h, 3 * ngroup, &rp, &ct, &wv, &nt)) {
         std::vector<int32_t> blk;
         for (int t = 0; t < npart; t++)
           for (int r0 = 0; r0 < h; r0 += nt * rp)
@@ -571,7 +581,7 @@ struct pconv_entropy_engine {
     // (r3, whole codec at 8 frames, host-driven chains: 2 / 3 / 4 groups 194-199 / 183-187 / 178-180 ms per
     // decode; at 4 frames two groups of two on the queued chain stay best: profiles/round3_decode_groups.txt);
     // eight make the chains wait for each other (4 hardware queues)
-    const int ngroups = host_plan(nimg).groups;
+    const int ngroups = plan.groups;
     groups.resize(ngroups);
     for (int k = 0, first = 0; k < ngroups; k++) {
       const int n = nimg / ngroups + (k < nimg % ngroups ? 1 : 0);
@@ -604,6 +614,7 @@ struct pconv_entropy_engine {
       if (g.flags_h) (void)hipHostFree(g.flags_h);
       freed(g.counter_d);
       if (g.done) (void)hipEventDestroy(g.done);
+      if (g.step_done) (void)hipEventDestroy(g.step_done);
       for (hipEvent_t &ev : g.enc_done)
         if (ev) (void)hipEventDestroy(ev);
       if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -854,7 +865,12 @@ struct pconv_entropy_engine {
     const auto t0 = std::chrono::steady_clock::now();
     // (polling a flag the table kernel publishes behind its rows instead -- the queued chain's protocol -- is
     // slower here: 183-192 vs 174-180 ms for the 8-frame decode, profiles/round4_decode_spin_poll.txt)
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (plan.blocking_sync) {
+      HIP_TRY(hipEventRecord(g.step_done, g.stream));
+      HIP_TRY(hipEventSynchronize(g.step_done));
+    } else {
+      HIP_TRY(hipStreamSynchronize(g.stream));
+    }
     const auto t1 = std::chrono::steady_clock::now();
     PC_TRY(decode_rows(g, s, cur));
     const auto t2 = std::chrono::steady_clock::now();
@@ -902,12 +918,11 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
     pconv_set_error("ee_create: bad argument");
     return nullptr;
   }
-  // Host-constrained rank: the runtime's waits (stream / event synchronisation of the drivers and the coder
-  // threads) sleep on an interrupt instead of spinning.  A device-wide flag of this process -- one process per
-  // GPU is the deployment model (test/trainDDP_Full.py:83-86); PCONV_ENGINE_BLOCKING_SYNC=0 / 1 forces it.
-  if (host_plan(nimg).blocking_sync && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess)
-    (void)hipGetLastError();  // (a runtime that refuses the flag on a live context: keep spinning, leave no stale error)
   pconv_entropy_engine *e = new pconv_entropy_engine();
+  // The host side of every call of this engine -- groups, threads per group, chain, sleeping or spinning waits --
+  // is decided here, once, from the rank's share of the host as it is NOW; decode reuses it (a changed affinity
+  // mask or LOCAL_WORLD_SIZE between create and decode cannot disagree with the groups that exist).
+  e->plan = host_plan(nimg);
   e->npart = npart; e->ngroup = ngroup; e->h = h; e->w = w; e->nimg = nimg;
   e->bias = bias; e->nlevels = nlevels; e->total = total; e->beta = beta;
   if (e->init(tile_weight) != PCONV_OK) {
@@ -956,6 +971,11 @@ int pconv_ee_host_plan(int nimg, int *groups, int *group_threads, int *queued_ch
   if (queued_chain) *queued_chain = p.queued_chain;
   if (blocking_sync) *blocking_sync = p.blocking_sync;
   return PCONV_OK;
+}
+
+int pconv_ee_wait_mode(const pconv_entropy_engine *e) {
+  PCONV_REQUIRE(e, "ee_wait_mode: null engine");
+  return e->plan.blocking_sync ? 1 : 0;
 }
 
 // step ranges the LAST group of the following encode calls is evaluated in (1: one piece; 0: back to the default,
@@ -1188,7 +1208,7 @@ int pconv_ee_decode(pconv_entropy_engine *e, const uint8_t *const *streams, cons
   //     host-driven: 94 / 103 ms for one frame, 110 / 113 for two, 141 / 137 for four, 212 / 197 for eight
   //     (four frames per group: 276 KB of rows per step); r3: from six frames on four groups, host-driven
   //     (8 frames: 178-180 ms; four groups on the queued chain 206-209).  PCONV_ENGINE_CHAIN=queued|host overrides.
-  const HostPlan plan = host_plan(e->nimg);
+  const HostPlan plan = e->plan;
   const int ng = (int)e->groups.size();
   const bool chained = plan.queued_chain != 0;
   std::vector<int> rcs(ng, PCONV_OK);

@@ -34,9 +34,10 @@ struct Pos {
 // An integer CDF row of the codec's shape (8 symbols, total 65536) as the coder's packed 16-byte row
 // (include/pconv_coder.h): uint16 c1 .. c7, then an auxiliary word -- bits 0-7 the label, bit 7 + k: c_k == 65536
 // (stored as 0), bit 15: the row does not have this shape (the coder then refuses it, as it refuses an int32 row
-// whose total is off).  16 bytes per symbol cross PCIe instead of 36 + 4.
-__device__ __forceinline__ uint4 pack_row16(const int32_t *row, unsigned label) {
-  unsigned aux = label & 0xffu;
+// whose total is off).  16 bytes per symbol cross PCIe instead of 36 + 4.  A label outside [0, 255] (the int32 rows
+// carry it unclipped and the coder answers "symbol out of range") is stored as 255, which the coder refuses the same way.
+__device__ __forceinline__ uint4 pack_row16(const int32_t *row, int32_t label) {
+  unsigned aux = (label < 0 || label > 255) ? 0xffu : (unsigned)label;
   unsigned hw[7];
   bool ok = row[0] == 0 && row[8] == 65536;
 #pragma unroll
@@ -877,7 +878,7 @@ __global__ void ee_tables8_kernel(EeGeom g, const float *__restrict__ y, int32_t
     row[0] = 0;
 #pragma unroll
     for (int i = 0; i < NS; i++) row[i + 1] = (int32_t)__shfl(cur, base_lane + i, 64);
-    if (live && q == 0) reinterpret_cast<uint4 *>(table)[(size_t)n * len + l] = pack_row16(row, 0u);
+    if (live && q == 0) reinterpret_cast<uint4 *>(table)[(size_t)n * len + l] = pack_row16(row, 0);
   }
   if (flags) {
     __syncthreads();  // every wave of the block has drained its stores (vmcnt(0) before the barrier)
@@ -926,7 +927,7 @@ __global__ void ee_tables_bulk_kernel(EeGeom g, const float *__restrict__ y, con
     if (packed) {  // (nstep == 8: checked on the host)
       int32_t row[9];
       gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, 8, bias, total, 1, row);
-      reinterpret_cast<uint4 *>(table)[r] = pack_row16(row, (unsigned)label);
+      reinterpret_cast<uint4 *>(table)[r] = pack_row16(row, label);
     } else {
       gmm_cdf_row<int32_t>(par[0], par[1], par[2], 3, nstep, bias, total, 1, table + r * (nstep + 1));
       labels[r] = label;

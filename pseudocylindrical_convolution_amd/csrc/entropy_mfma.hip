@@ -103,7 +103,6 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
     EeGeom g, const int4 *__restrict__ blocks, int rp_n, int ct_n, const float *__restrict__ x, int shared_input,
     const float *__restrict__ wfrag, const float *__restrict__ bias, const float *__restrict__ slope,
     const float *__restrict__ residual, float *__restrict__ y, int pad_out, int s_lo, int s_hi) {
-  constexpr int RED = CIN * KK;
   constexpr int STEPS = steps_of(CIN), QUADS = quads_of(CIN), FRAG = frag_floats(CIN);
   constexpr int COUT = 3 * (CIN == 14 ? 14 : CIN / 3);  // 3 per group
   static_assert(COUT <= 16 * kMT, "three output tiles");
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(WAVES * kWave, kNT == 1 ? 3 : 2) void ee_conv_bulk_
   if (col >= width) return;
   // four consecutive outputs per accumulator tile: 8-byte pieces (a pixel is 168 bytes, an output quad starts at a
   // multiple of 16: both 8-byte aligned); the whole schedule (no step range) skips the per-output range test
-  const bool whole = s_lo <= 0 && s_hi > g.h * g.npart + g.w + g.ngroup;  // (uniform)
+  const bool whole = s_lo <= 0 && s_hi >= g.h * g.npart + g.w + g.ngroup - 2;  // (uniform; the schedule has rows + w + ngroup - 2 steps)
   typedef float f2 __attribute__((ext_vector_type(2)));
   const float *bset = bias + set * COUT, *sset = slope ? slope + set * COUT : nullptr;
 #pragma unroll
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(WAVES * kWave, 2) void ee_conv_bulk_mfma4_kernel(
   }
   // way out (bias, slope, the residual fetched in the prologue), 8-byte stores
   if (col >= width) return;
-  const bool whole = s_lo <= 0 && s_hi > g.h * g.npart + g.w + g.ngroup;
+  const bool whole = s_lo <= 0 && s_hi >= g.h * g.npart + g.w + g.ngroup - 2;
   const float *bset = bias + set * COUT, *sset = slope ? slope + set * COUT : nullptr;
   const int plane = tile * h + row + col;
 #pragma unroll

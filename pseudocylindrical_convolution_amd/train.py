@@ -9,12 +9,15 @@ optimisers (entropy model / transforms + quantiser levels, the histogram "gradie
 applied by its own SGD), gradient accumulation over `acc_batch` steps with clipping, and the
 checkpoint naming follow the reference.  What differs: ranks come from the launcher's environment
 (RANK / LOCAL_RANK / WORLD_SIZE) instead of mp.spawn, every path is an argument, and
-`--synthetic N` trains on generated images where no dataset exists."""
+`--synthetic N` / `--procedural N` train on generated images where no dataset exists, and
+`--time-budget S` ends the run after S seconds of wall time (the epoch in flight stops at its next
+step, is tested and saved as usual)."""
 from __future__ import print_function
 
 import argparse
 import os
 import sys
+import time
 from itertools import chain
 
 import torch
@@ -24,7 +27,8 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 from . import model_zoo_v2
 from .PCONV_operator import Logger, ModuleSaver, MultiProject, SSIM
 from .RDMetric import mse_tb
-from .SphereDataset import SphereDataSet, SyntheticSphereDataSet, load_train_test_distribute
+from .SphereDataset import (ProceduralSphereDataSet, SphereDataSet, SyntheticSphereDataSet,
+                            load_train_test_distribute)
 from .model_zoo_v2 import AccGrad
 
 
@@ -60,6 +64,8 @@ def train(args, model, device, train_loader, optimizer, optimizer_quant, epoch, 
         if not data.shape[0] == args.batch_size:
             continue
         if args.max_steps and batch_idx >= args.max_steps:
+            break
+        if getattr(args, 'deadline', None) and time.monotonic() >= args.deadline:
             break
         data = data.to(device)
         optimizer.zero_grad()
@@ -129,6 +135,11 @@ def setup(rank, world_size, backend):
 
 
 def make_datasets(args):
+    if args.procedural:
+        ntest = max(args.test_batch_size, min(8, args.procedural // 8))
+        train_data = ProceduralSphereDataSet(args.procedural, args.height, args.width, seed=args.seed * 2 + 1)
+        test_data = ProceduralSphereDataSet(ntest, args.height, args.width, seed=args.seed * 2 + 2)
+        return train_data, test_data, train_data.values()
     if args.synthetic:
         ntest = max(args.test_batch_size, args.synthetic // 8)
         train_data = SyntheticSphereDataSet(args.synthetic, args.height, args.width, seed=1)
@@ -213,7 +224,11 @@ def Job(rank, world_size, args):
     log.log('lr:{}'.format(args.lr))
     log.log('valid dims:{} \t alpha:{}'.format(args.valid_dim, args.alpha))
     history = []
+    args.deadline = time.monotonic() + args.time_budget if args.time_budget > 0 else None
     for epoch in range(1, args.epochs + 1):
+        if args.deadline and time.monotonic() >= args.deadline:
+            log.log('time budget of {} s used up after {} epoch(s)'.format(args.time_budget, epoch - 1))
+            break
         if args.base or (not args.init and epoch % 4 == 1):
             last = train(args, model, device, train_loader, optimizer_other, optimizer_quant, epoch, log, pr1, pr2, False)
         else:
@@ -268,6 +283,10 @@ def build_parser():
     parser.add_argument('--test-list', default=None)
     parser.add_argument('--values', default=None, help='pickle: image name -> value, for the balanced sampler')
     parser.add_argument('--synthetic', type=int, default=0, help='train on this many generated images')
+    parser.add_argument('--procedural', type=int, default=0,
+                        help='train on this many procedural images (gradients, textures, hard-edged shapes)')
+    parser.add_argument('--time-budget', type=float, default=0,
+                        help='stop after this many seconds of wall time (0: run all epochs)')
     parser.add_argument('--height', type=int, default=512)
     parser.add_argument('--width', type=int, default=1024)
     parser.add_argument('--workers', type=int, default=4)

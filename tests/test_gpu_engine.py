@@ -248,15 +248,23 @@ def test_host_constrained_plan_decodes_the_same_symbols(hip_backend, monkeypatch
     quota.write_text("1600000 100000")                       # 16 CPUs ...
     monkeypatch.setenv("PCONV_CGROUP_CPU_MAX", str(quota))
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")              # ... shared by 8 ranks: 2 per rank, 5 frames
-    monkeypatch.setenv("PCONV_ENGINE_BLOCKING_SYNC", "0")    # (the device-wide wait policy stays as it is for the other tests)
     lib = roomy.lib
+    assert lib.pconv_ee_wait_mode(roomy.handle) == 0         # a roomy rank keeps the runtime's spinning waits
     import ctypes
     plan = [ctypes.c_int(-1) for _ in range(4)]
     assert lib.pconv_ee_host_plan(n, *[ctypes.addressof(v) for v in plan]) == 0
     assert [v.value for v in plan[:3]] == [min(2, lib.pconv_ee_host_cpus()), 1, 0]
     tight = EntropyEngine(ent, h, w, n, "cuda:0")
+    # sleeping waits = blocking EVENTS of this engine (hipEventBlockingSync), no device-wide schedule flag: the plan
+    # is fixed at creation and the engine reports it
+    assert plan[3].value == 1 and lib.pconv_ee_wait_mode(tight.handle) == 1
     assert tight.encode(sym) == streams
     assert torch.equal(tight.decode(streams), sym)
+    # the plan is the engine's, not the environment's: a roomier environment at decode time changes nothing
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert lib.pconv_ee_wait_mode(tight.handle) == 1
+    assert torch.equal(tight.decode(streams), sym)
+    assert lib.pconv_ee_wait_mode(roomy.handle) == 0
     # one CPU: a single group, one thread
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
     one = EntropyEngine(ent, h, w, n, "cuda:0")

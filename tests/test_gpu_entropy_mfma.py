@@ -97,3 +97,33 @@ def test_four_block_form_of_the_matrix_core_kernel_agrees(hip_backend, monkeypat
     assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=ranges) == ref
     monkeypatch.setenv("PCONV_EE_MFMA_FORM", "16x4")
     assert _encode(ent, sym, h, w, n, "mfma", monkeypatch, ranges=ranges) == ref
+
+
+@pytest.mark.parametrize("h,w", [(4, 65), (2, 81)])
+def test_odd_widths_keep_the_vector_kernel(hip_backend, monkeypatch, h, w):
+    """a padded row of an odd width ends on half a 16-byte piece of the matrix-core kernel's patch loads: the engine
+    takes the vector kernel for such shapes (csrc/engine.cpp; only direct pconv_ee_create users meet them -- the
+    codec's symbol planes are Dtow(2) outputs).  Same streams as PCONV_EE_BULK=valu, and the decoder (step kernel)
+    reads them back."""
+    from pseudocylindrical_convolution_amd.engine import EntropyEngine
+    ent = _ent(29)
+    sym = torch.randint(0, 8, (16, 14, h, w), generator=torch.Generator().manual_seed(31 + w)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    ref = _encode(ent, sym, h, w, 1, "valu", monkeypatch)
+    out = _encode(ent, sym, h, w, 1, "mfma", monkeypatch)
+    assert out == ref
+    back = EntropyEngine(ent, h, w, 1, "cuda:0").decode(out)
+    assert torch.equal(back, sym)
+
+
+def test_packed_rows_refuse_a_label_outside_the_alphabet(hip_backend, monkeypatch):
+    """a symbol such as 256 must not be folded to 0 by the packed 16-byte rows: the coder answers as it does for the
+    int32 rows (include/pconv_coder.h: symbol out of range)"""
+    from pseudocylindrical_convolution_amd._native import PconvError
+    ent = _ent(37)
+    h, w = 2, 64
+    sym = torch.randint(0, 8, (16, 14, h, w), generator=torch.Generator().manual_seed(41)).float().cuda()
+    sym = ent.fill(sym).contiguous()
+    sym[5, 3, 1, 2] = 256.0
+    with pytest.raises(PconvError):
+        _encode(ent, sym, h, w, 1, "mfma", monkeypatch)
