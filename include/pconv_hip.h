@@ -158,6 +158,14 @@ int pconv_quant(const float *x, const float *weight, float *level_tab, float *ou
  * x otherwise -- the same three roundings as the reference's masked assignments, in one pass. */
 int pconv_leaky_clip(float *x, long long n, void *stream);
 
+/* Frame I/O at the PCIe boundary: the device side of img2tensor / tensor2img (pseudo_codec.py:215-221).
+ * u8_to_f32: in = n interleaved uint8 images (n, height, width, 3) ON THE DEVICE (copied there as they come from the
+ * image file), out = float32 (n, 3, height, width) = float(u8) / 255.f, correctly rounded (the reference's numpy
+ * float32 division).  f32_to_u8: out = (uint8)(int)(x * 255.f), numpy's float32 -> uint8 cast of tensor2img (truncation,
+ * low byte kept).  width % 4 == 0; image 4-byte aligned, tensor 16-byte aligned. */
+int pconv_frames_u8_to_f32(const uint8_t *in, float *out, int n, int height, int width, void *stream);
+int pconv_frames_f32_to_u8(const float *in, uint8_t *out, int n, int height, int width, void *stream);
+
 /* PseudoDQuantOp.forward  (pseudo_dquant_cuda.cu:24-70)
  * weight (wc, levels) raw parameter, level_tab (wc, levels) scratch */
 int pconv_dquant(const float *x, const float *weight, float *level_tab, float *out,

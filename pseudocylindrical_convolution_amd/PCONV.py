@@ -11,6 +11,7 @@ There is no CPU path here: every forward needs the HIP library and a GPU tensor.
 """
 import ctypes
 import functools
+import os
 import weakref
 
 import numpy as np
@@ -1125,6 +1126,7 @@ def packed_wino_weight(owner, weight, stream):
 
 
 CONV3X3_DEFAULT = "wino42"
+WINO_ROW_SPLIT = os.environ.get("PCONV_WINO_SPLIT", "1") == "1"
 
 
 def conv3x3_mode():
@@ -1236,6 +1238,38 @@ def leaky_clip_(x):
     return x
 
 
+def frames_u8_to_f32(img, out=None):
+    """device side of img2tensor (pseudo_codec.py:215-217): uint8 (n, H, W, 3) GPU tensor -> float32 (n, 3, H, W),
+    float(u8) / 255 exactly as the reference's host division; the bus carried a quarter of the bytes"""
+    _require_gpu(img, "frames_u8_to_f32")
+    if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3 or not img.is_contiguous():
+        raise PconvError("frames_u8_to_f32: contiguous uint8 (n, H, W, 3) expected")
+    n, h, w, _ = img.shape
+    if out is None:
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=img.device)
+    elif tuple(out.shape) != (n, 3, h, w) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != img.device:
+        raise PconvError("frames_u8_to_f32: out must be contiguous float32 (n, 3, H, W) on the image's device")
+    with _HbmTimed("frames_u8_to_f32_kernel", "img2tensor n%d" % n, 5.0 * img.numel(), img.device):
+        call("pconv_frames_u8_to_f32", _ptr(img), _ptr(out), n, h, w, _stream(img.device))
+    return out
+
+
+def frames_f32_to_u8(x, out=None):
+    """device side of tensor2img (pseudo_codec.py:219-221): float32 (n, 3, H, W) -> uint8 (n, H, W, 3),
+    (uint8)(int)(x * 255) as numpy's cast does it"""
+    _require_gpu(x, "frames_f32_to_u8")
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
+        raise PconvError("frames_f32_to_u8: contiguous float32 (n, 3, H, W) expected")
+    n, _, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=x.device)
+    elif tuple(out.shape) != (n, h, w, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != x.device:
+        raise PconvError("frames_f32_to_u8: out must be contiguous uint8 (n, H, W, 3) on the tensor's device")
+    with _HbmTimed("frames_f32_to_u8_kernel", "tensor2img n%d" % n, 5.0 * x.numel(), x.device):
+        call("pconv_frames_f32_to_u8", _ptr(x), _ptr(out), n, h, w, _stream(x.device))
+    return out
+
+
 def tile_gdn(owner, x, gamma, beta, inverse, col_limit=None, npart=0, residual=None, ring=0):
     """PseudoGDNV2.forward in one launch: x / sqrt(beta + gamma x^2) (inverse: x * sqrt)
     (+ residual), zeros from each tile's col_limit on.  gamma (ch, ch), beta (ch):
@@ -1295,39 +1329,71 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
     aligned = want_wino and _aligned8(out) and (residual is None or _aligned8(residual))
     # F(4x2, 3x3) works on 64-cout blocks: a 96-cout layer would run a third of them empty (and its 24 chunks are
     # head and tail of the unrolled loop, no steady state): measured 0.475 vs 0.374 ms, it stays with F(2x2, 3x3)
-    # ... and on 8-row blocks: with more than an eighth of the computed rows outside the tensor (34 -> 40, 18 -> 24
-    # output rows: the "+1 halo" layers of ResidualBlockV2 at the small scales) F(2x2)'s 4-row blocks are level or ahead
-    wino42 = (aligned and (mode == "wino42!" or (mode == "wino42" and cout % 64 == 0 and (ho + 7) // 8 * 8 * 8 <= 9 * ho)) and
-              _native.hip_lib().pconv_wino42_supported(cin, h, w, cout, 1 if d2w else 0) == 1)
-    wino = aligned and not wino42 and _native.hip_lib().pconv_wino_supported(cin, h, w, cout, 1 if d2w else 0) == 1
-    if want_wino and not (wino or wino42):
+    # ... and on 8-row blocks.  Row counts that leave a remainder of up to four rows (66, 34, 18, 10: the "+1 halo"
+    # layers of ResidualBlockV2) are SPLIT (r6): the whole 8-row blocks on F(4x2), the remainder as one 4-row block
+    # row of F(2x2) in a second launch over row views of the same tensors -- before, 66 rows ran a ninth F(4x2) block
+    # for two rows and 34 / 18 / 10 rows went to F(2x2) altogether.  PCONV_WINO_SPLIT=0: the round-5 rule (A/B).
+    lib = _native.hip_lib()
+    d2 = 1 if d2w else 0
+    main_rows = 0
+    if aligned and mode == "wino42" and cout % 64 == 0 and ho > 8 and 0 < ho % 8 <= 4 and WINO_ROW_SPLIT and \
+            lib.pconv_wino42_supported(cin, ho // 8 * 8 + 2, w, cout, d2) == 1 and \
+            lib.pconv_wino_supported(cin, ho % 8 + 2, w, cout, d2) == 1:
+        main_rows = ho // 8 * 8
+    wino42 = (aligned and main_rows == 0 and
+              (mode == "wino42!" or (mode == "wino42" and cout % 64 == 0 and (ho + 7) // 8 * 8 * 8 <= 9 * ho)) and
+              lib.pconv_wino42_supported(cin, h, w, cout, d2) == 1)
+    wino = aligned and main_rows == 0 and not wino42 and lib.pconv_wino_supported(cin, h, w, cout, d2) == 1
+    if want_wino and not (wino or wino42 or main_rows):
         # a plain 3x3 stride-1 layer that Winograd was selected for went to the direct kernel (shape not
         # taken, or output / residual rows not 8-byte aligned): counted, so that the choice is never silent
         key = (cin, h, w, cout, bool(d2w))
         conv_fallbacks[key] = conv_fallbacks.get(key, 0) + 1
     probe = conv_probe
+
+    def winograd(use42, r0, rows):
+        """output rows [r0, r0 + rows) by one Winograd launch over row views (whole tensors: r0 = 0, rows = ho)"""
+        whole = r0 == 0 and rows == ho
+        rs = 2 if d2w else 1
+        xv = x if whole else x[:, :, r0:r0 + rows + 2]
+        ov = out if whole else out[:, :, rs * r0:rs * (r0 + rows)]
+        rv = residual if (whole or residual is None) else residual[:, :, r0:r0 + rows]
+        if probe is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(x.device))
+        views = _views(xv, ov, rv)
+        call("pconv_conv3x3_wino42" if use42 else "pconv_conv3x3_wino", _ptr(xv),
+             _ptr(packed_wino42_weight(owner, weight, stream) if use42 else packed_wino_weight(owner, weight, stream)),
+             _ptr(bias.detach()) if bias is not None else None, _ptr(ov), tn, cin, rows + 2, w, cout,
+             1 if slope is not None else 0, _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit),
+             int(npart), _ptr(rv), 1 if trim else 0, d2, ctypes.addressof(views), stream)
+        if probe is not None:
+            e1.record(torch.cuda.current_stream(x.device))
+            flops = 2.0 * cin * 9 * cout * tn * rows * wo * _VALID_FRACTION
+            nbytes = 4.0 * tn * _VALID_FRACTION * (cin * (rows + 2) * w + cout * rows * wo * (1 + (residual is not None)))
+            label = "3x3 s1 %d->%d w%d" % (cin, cout, wo) + ("" if whole else (" rows %d of %d" % (rows, ho)))
+            probe.records.append(("wino42_conv3x3_kernel" if use42 else "wino_conv3x3_kernel", label, flops, e0, e1, nbytes))
+
+    if main_rows:
+        winograd(True, 0, main_rows)
+        winograd(False, main_rows, ho - main_rows)
+        return out
+    if wino or wino42:
+        winograd(wino42, 0, ho)
+        return out
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(x.device))
-    if wino or wino42:
-        views = _views(x, out, residual)
-        call("pconv_conv3x3_wino42" if wino42 else "pconv_conv3x3_wino", _ptr(x),
-             _ptr(packed_wino42_weight(owner, weight, stream) if wino42 else packed_wino_weight(owner, weight, stream)),
-             _ptr(bias.detach()) if bias is not None else None, _ptr(out), tn, cin, h, w, cout,
-             1 if slope is not None else 0, _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit),
-             int(npart), _ptr(residual), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
-    else:
-        packed = packed_conv_weight(owner, weight, stream)
-        views = _views(x, out, residual, gate)
-        call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
-             tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
-             _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
-             _ptr(residual), _ptr(gate), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
+    packed = packed_conv_weight(owner, weight, stream)
+    views = _views(x, out, residual, gate)
+    call("pconv_conv2d", _ptr(x), _ptr(packed), _ptr(bias.detach()) if bias is not None else None, _ptr(out),
+         tn, cin, h, w, cout, k, int(stride), 4 if sigmoid else (1 if slope is not None else 0),
+         _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit), int(npart),
+         _ptr(residual), _ptr(gate), 1 if trim else 0, 1 if d2w else 0, ctypes.addressof(views), stream)
     if probe is not None:
         e1.record(torch.cuda.current_stream(x.device))
         flops = 2.0 * cin * k * k * cout * tn * ho * wo * _VALID_FRACTION
-        kernel = "wino42_conv3x3_kernel" if wino42 else ("wino_conv3x3_kernel" if wino else
-                                                         conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w))
+        kernel = conv_kernel_name(cout, k, stride, cin=cin, pixels=tn * h * w)
         # algorithmic HBM bytes: the input once, the output once, residual / gate once each
         nbytes = 4.0 * tn * _VALID_FRACTION * (cin * h * w + cout * ho * wo * (1 + (residual is not None) + (gate is not None)))
         probe.records.append((kernel, "%dx%d s%d %d->%d w%d" % (k, k, stride, cin, cout, wo), flops, e0, e1, nbytes))

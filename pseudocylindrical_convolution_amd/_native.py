@@ -38,6 +38,8 @@ _HIP_SIGNATURES = {
     "pconv_quant": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "pconv_dquant": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "pconv_leaky_clip": [P, LL, P],
+    "pconv_frames_u8_to_f32": [P, P, I, I, I, P],
+    "pconv_frames_f32_to_u8": [P, P, I, I, I, P],
     "pconv_project": [P, P, P, I, I, I, I, I, I, I, I, P],
     "pconv_context_reshape": [P, P, I, I, I, I, I, P],
     "pconv_mask_constrain": [P, I, I, I, I, I, P],

@@ -296,13 +296,35 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
     EeGeom g, const float *__restrict__ x, int shared_input, const float *__restrict__ wp,
     const uint32_t *__restrict__ tapoff, const float *__restrict__ bias, const float *__restrict__ slope,
     const float *__restrict__ residual, float *__restrict__ y, int pad_out, int first_plane, int psum,
-    int contiguous) {
+    int contiguous, int xcd_split, int xcd_nplane) {
   constexpr int kWaves = BLOCK / kWave;
   constexpr int SLOTS = ITER * kWave;
   static_assert(SLOTS == slab_slots(CIN), "ITER must cover the padded reduction length");
-  const int part = blockIdx.x, split = gridDim.x;
-  const int plane = first_plane + blockIdx.y;
-  const int pn = blockIdx.z;  // replica-major image index: set * nimg + img
+  // Which (part, plane, set, image) a workgroup is.  3-D grid: read off blockIdx.  xcd_split > 0 (r6): a 1-D grid
+  // in XCD-MAJOR order -- workgroup b runs on XCD b % 8 (round-robin dispatch; an assumption for speed only), and the
+  // workgroups of one XCD take a CONTIGUOUS range of the (set, plane, image, part) order, so that the ~42 / 8 weight
+  // slabs a launch's XCD needs are fetched into ITS L2 once instead of all 42 into every L2 (every launch starts
+  // with cold L2s: the slabs were 7/8 of the re-fetched bytes), and neighbouring planes of one set -- whose
+  // windows overlap -- meet in one L2.
+  int part, split, plane, pn;
+  if (xcd_split > 0) {
+    const int npn = 3 * g.nimg;
+    const int nb = xcd_split * xcd_nplane * npn;
+    const int per = (nb + 7) >> 3;
+    const int v = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (v >= nb) return;  // (uniform)
+    split = xcd_split;
+    part = v % split;
+    int q = v / split;
+    const int im = q % g.nimg;
+    q /= g.nimg;
+    plane = first_plane + q % xcd_nplane;
+    pn = (q / xcd_nplane) * g.nimg + im;
+  } else {
+    part = blockIdx.x, split = gridDim.x;
+    plane = first_plane + blockIdx.y;
+    pn = blockIdx.z;  // replica-major image index: set * nimg + img
+  }
   const int set = (pn >= g.nimg) + (pn >= 2 * g.nimg);
   const int img = pn - set * g.nimg;
   typedef const __attribute__((address_space(4))) int32_t const_i32_t;
@@ -986,11 +1008,15 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;
   const uint32_t *tap = cin == g->ngroup ? g->tap_in : g->tap_hid;
-  const dim3 grid((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));
-  PCONV_REQUIRE(grid.z <= 65535u && grid.y <= 65535u, "ee_conv: too many images for one launch");
+  // PCONV_EE_XCD: 1 (default) = the 1-D XCD-major workgroup order (see the kernel), 0 = the 3-D grid of rounds 3-5
+  static const int xcd = getenv("PCONV_EE_XCD") ? atoi(getenv("PCONV_EE_XCD")) : 1;
+  const long long nb = (long long)split * nplane * 3 * g->nimg;
+  PCONV_REQUIRE(3 * g->nimg <= 65535 && nplane <= 65535 && nb < (1LL << 30), "ee_conv: too many images for one launch");
+  const dim3 grid = xcd ? dim3((unsigned)(8 * ((nb + 7) / 8)), 1, 1) : dim3((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));
+  const int xs = xcd ? split : 0;
 #define EE_LAUNCH_J(CIN, ITER, BLK, PJ)                                                                      \
   hipLaunchKernelGGL((ee_step_kernel<CIN, ITER, BLK, PJ>), grid, dim3(BLK), 0, as_stream(stream), *g, x,     \
-                     shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum, contig)
+                     shared_input, packed_w, tap, bias, slope, residual, y, pad_out, first_plane, psum, contig, xs, nplane)
 #define EE_LAUNCH_B(CIN, ITER, BLK)                          \
   if (joint == 2 && ITER <= 20 && ppw >= 2) {                \
     EE_LAUNCH_J(CIN, ITER, BLK, (ITER <= 20 ? 2 : 1));       \

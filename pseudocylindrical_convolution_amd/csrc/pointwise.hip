@@ -406,6 +406,84 @@ extern "C" int pconv_leaky_clip(float *x, long long n, void *stream) {
   return PCONV_OK;
 }
 
+// Frame I/O at the PCIe boundary (pseudo_codec.py:215-221).  The reference converts on the host and moves fp32 over
+// the bus: img2tensor = uint8 HWC -> float32 CHW / 255. -> .to(device); tensor2img = (data * 255.).to('cpu') ->
+// astype(uint8).  Here the bus carries the uint8 image (a quarter of the bytes) and the SAME arithmetic runs on the
+// device: float(u8) / 255.f correctly rounded (numpy's float32 division), and (uint8)(int)(v * 255.f) -- numpy's
+// float32 -> uint8 cast truncates toward zero and keeps the low byte (ClipData leaks past [0, 1]: 1.004 * 255 = 256.02
+// -> 0 there and here).  One thread owns 4 consecutive pixels of a row: 12 bytes of the interleaved image as three
+// 32-bit words, one 16-byte piece per colour plane.
+__global__ void frames_u8_to_f32_kernel(const uint32_t *__restrict__ in, float *__restrict__ out, long long plane,
+                                        long long nquad) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long qpp = plane / 4;  // pixel quads per frame
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+    const uint32_t a = in[3 * q], b = in[3 * q + 1], c = in[3 * q + 2];
+    // bytes: a = p0c0 p0c1 p0c2 p1c0 | b = p1c1 p1c2 p2c0 p2c1 | c = p2c2 p3c0 p3c1 p3c2
+    const unsigned px[4][3] = {{a & 255u, (a >> 8) & 255u, (a >> 16) & 255u},
+                               {a >> 24, b & 255u, (b >> 8) & 255u},
+                               {(b >> 16) & 255u, b >> 24, c & 255u},
+                               {(c >> 8) & 255u, (c >> 16) & 255u, c >> 24}};
+    const long long n = q / qpp, r = q - n * qpp;
+    float *base = out + n * 3 * plane + 4 * r;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      float4 v;
+      v.x = __fdiv_rn((float)px[0][ch], 255.f);
+      v.y = __fdiv_rn((float)px[1][ch], 255.f);
+      v.z = __fdiv_rn((float)px[2][ch], 255.f);
+      v.w = __fdiv_rn((float)px[3][ch], 255.f);
+      *reinterpret_cast<float4 *>(base + ch * plane) = v;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned to_u8_like_numpy(float v) { return (unsigned)(int)(v * 255.f) & 255u; }
+
+__global__ void frames_f32_to_u8_kernel(const float *__restrict__ in, uint32_t *__restrict__ out, long long plane,
+                                        long long nquad) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long qpp = plane / 4;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+    const long long n = q / qpp, r = q - n * qpp;
+    const float *base = in + n * 3 * plane + 4 * r;
+    unsigned px[4][3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float4 v = *reinterpret_cast<const float4 *>(base + ch * plane);
+      px[0][ch] = to_u8_like_numpy(v.x), px[1][ch] = to_u8_like_numpy(v.y);
+      px[2][ch] = to_u8_like_numpy(v.z), px[3][ch] = to_u8_like_numpy(v.w);
+    }
+    out[3 * q] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
+    out[3 * q + 1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
+    out[3 * q + 2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+  }
+}
+
+extern "C" int pconv_frames_u8_to_f32(const uint8_t *in, float *out, int n, int height, int width, void *stream) {
+  PCONV_REQUIRE(in && out && n > 0 && height > 0 && width > 0, "frames_u8_to_f32: bad argument");
+  PCONV_REQUIRE(width % 4 == 0, "frames_u8_to_f32: the width must be a multiple of 4");
+  PCONV_REQUIRE((reinterpret_cast<uintptr_t>(in) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "frames_u8_to_f32: the image must be 4-byte aligned, the tensor 16-byte aligned");
+  const long long plane = (long long)height * width, nquad = (long long)n * plane / 4;
+  hipLaunchKernelGGL(frames_u8_to_f32_kernel, dim3(pconv_grid(nquad)), dim3(kBlock), 0, as_stream(stream),
+                     reinterpret_cast<const uint32_t *>(in), out, plane, nquad);
+  PCONV_LAUNCH_CHECK("frames_u8_to_f32");
+  return PCONV_OK;
+}
+
+extern "C" int pconv_frames_f32_to_u8(const float *in, uint8_t *out, int n, int height, int width, void *stream) {
+  PCONV_REQUIRE(in && out && n > 0 && height > 0 && width > 0, "frames_f32_to_u8: bad argument");
+  PCONV_REQUIRE(width % 4 == 0, "frames_f32_to_u8: the width must be a multiple of 4");
+  PCONV_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0,
+                "frames_f32_to_u8: the image must be 4-byte aligned, the tensor 16-byte aligned");
+  const long long plane = (long long)height * width, nquad = (long long)n * plane / 4;
+  hipLaunchKernelGGL(frames_f32_to_u8_kernel, dim3(pconv_grid(nquad)), dim3(kBlock), 0, as_stream(stream), in,
+                     reinterpret_cast<uint32_t *>(out), plane, nquad);
+  PCONV_LAUNCH_CHECK("frames_f32_to_u8");
+  return PCONV_OK;
+}
+
 extern "C" int pconv_project(const float *in, const float *tf, float *out, int n, int c,
                              int height, int width, int nview, int h_out, int w_out, int nearest,
                              void *stream) {

@@ -143,6 +143,20 @@ class CodecEngine(object):
         self.enc = encoder if encoder is not None else PC.PseudoEncoder(valid_dim, device_id)
         self.dec = decoder if decoder is not None else PC.PseudoDecoder(valid_dim, device_id)
         self._engines = {}
+        # bench.py: a list that receives (phase, start event, end event) per call -- analysis, entropy_encode,
+        # entropy_decode, synthesis -- recorded in the caller's stream (None: no events)
+        self.phase_probe = None
+
+    def _mark(self):
+        if self.phase_probe is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
+    def _phase(self, name, e0, e1):
+        if self.phase_probe is not None and e0 is not None and e1 is not None:
+            self.phase_probe.append((name, e0, e1))
 
     def _engine(self, which, h, w, nimg, slot=0):
         key = (which, h, w, nimg, slot)
@@ -272,7 +286,9 @@ class CodecEngine(object):
         # then only pipeline the entropy stage (GPU tables of chunk k+1 beside the CPU coding of chunk k)
         batched = n > 1 and hasattr(self.enc.encoder, "forward_range") and \
             self._split(self.ANALYSIS_SPLIT, self.enc.encoder.net, 1) > 0
+        t0 = self._mark()
         sym_all = self.symbols(frames).contiguous() if batched else None
+        t1 = self._mark()
         pending, out = [], []
         try:
             for k, lo in enumerate(range(0, n, chunk)):
@@ -295,6 +311,10 @@ class CodecEngine(object):
             raise
         for eng in pending:
             out += eng.encode_end()
+        if batched:
+            # (every coder thread has been joined: the GPU part of the entropy stage is over, the end event marks now)
+            self._phase("analysis", t0, t1)
+            self._phase("entropy_encode", t1, self._mark())
         return out
 
     # frames per pipeline stage of decode(); 0 = decode all frames of a call together, then run the
@@ -312,8 +332,13 @@ class CodecEngine(object):
         tiles = self.dec.npart
         chunk = self.DECODE_CHUNK
         if chunk <= 0 or n <= chunk:
+            t0 = self._mark()
             sym = self._engine("dec", 2 * h, 2 * w, n).decode(streams)
-            return self.reconstruct(sym, n)
+            t1 = self._mark()
+            rec = self.reconstruct(sym, n)
+            self._phase("entropy_decode", t0, t1)
+            self._phase("synthesis", t1, self._mark())
+            return rec
         chunks = [streams[i:i + chunk] for i in range(0, n, chunk)]
         side = torch.cuda.Stream(device=self.device)
         box = {}
@@ -342,3 +367,71 @@ class CodecEngine(object):
             if worker is not None:
                 worker.join()
         return torch.cat(out, 0)
+
+
+class FramePipe(object):
+    """Frames between pinned host memory and HBM beside the codec's compute (the two ends of the reference's
+    flow, pseudo_codec.py:236-247 and 249-268: imread -> img2tensor -> .cuda() ... tensor2img -> imwrite).
+
+    The bus carries the uint8 image as the image file holds it (H, W, 3) -- a quarter of the reference's fp32
+    bytes -- on two copy streams of its own, double-buffered: while the codec works on batch k, batch k + 1 is
+    uploaded and batch k - 1's reconstruction is downloaded.  img2tensor's division and tensor2img's cast run on
+    the device with the reference's arithmetic (PCONV.frames_u8_to_f32 / frames_f32_to_u8).  Copies are issued
+    frame by frame (25 MB at 4096x2048: half a millisecond each) so that the entropy engine's small, latency-bound
+    transfers never queue behind one long DMA."""
+
+    def __init__(self, n, height, width, device):
+        self.n, self.h, self.w = int(n), int(height), int(width)
+        self.device = torch.device(device)
+        self.ops = backend.ops()
+        if not hasattr(self.ops, "frames_u8_to_f32"):
+            raise PconvError("FramePipe needs the HIP backend")
+        shape = (self.n, self.h, self.w, 3)
+        self.up, self.down = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        self.dev_in = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.dev_out = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.host_out = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.frames = torch.empty((self.n, 3, self.h, self.w), dtype=torch.float32, device=self.device)
+        ev = lambda: [torch.cuda.Event() for _ in range(2)]
+        self.up_done, self.in_free, self.out_ready, self.down_done = ev(), ev(), ev(), ev()
+        self._in_used, self._out_used = [False, False], [False, False]
+
+    def prefetch(self, host_u8, slot):
+        """queue the upload of a batch (pinned uint8 (n, H, W, 3)) into input slot `slot` on the upload stream"""
+        if tuple(host_u8.shape) != tuple(self.dev_in[slot].shape) or host_u8.dtype != torch.uint8:
+            raise PconvError("FramePipe.prefetch: uint8 %s expected" % (tuple(self.dev_in[slot].shape),))
+        with torch.cuda.stream(self.up):
+            if self._in_used[slot]:
+                self.up.wait_event(self.in_free[slot])     # the conversion that read this slot last has run
+            for i in range(self.n):
+                self.dev_in[slot][i].copy_(host_u8[i], non_blocking=True)
+            self.up_done[slot].record(self.up)
+
+    def take(self, slot):
+        """the uploaded batch of `slot` as float32 (n, 3, H, W) in the caller's stream (img2tensor's arithmetic)"""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.up_done[slot])
+        self.ops.frames_u8_to_f32(self.dev_in[slot], self.frames)
+        self.in_free[slot].record(cur)
+        self._in_used[slot] = True
+        return self.frames
+
+    def give(self, rec, slot):
+        """queue tensor2img + the download of a reconstruction (n, 3, H, W) into host_out[slot]; returns that
+        pinned tensor (valid once down_done[slot] has completed: wait(slot))"""
+        cur = torch.cuda.current_stream(self.device)
+        if self._out_used[slot]:
+            cur.wait_event(self.down_done[slot])           # the previous download out of this slot has finished
+        self.ops.frames_f32_to_u8(rec.contiguous(), self.dev_out[slot])
+        self.out_ready[slot].record(cur)
+        with torch.cuda.stream(self.down):
+            self.down.wait_event(self.out_ready[slot])
+            for i in range(self.n):
+                self.host_out[slot][i].copy_(self.dev_out[slot][i], non_blocking=True)
+            self.down_done[slot].record(self.down)
+        self._out_used[slot] = True
+        return self.host_out[slot]
+
+    def wait(self, slot):
+        self.down_done[slot].synchronize()
+        return self.host_out[slot]

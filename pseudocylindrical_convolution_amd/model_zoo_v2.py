@@ -68,15 +68,17 @@ class TileConv2d(nn.Conv2d):
     only needs columns < widths_t(base) + (wo - base), base = tile width of the
     scale the output lives in; 64-column blocks beyond that are written as zeros
     without being computed (they are dead: every consumer either trims them or
-    never reads them).  Without fusion support (CPU oracle backend,
-    PCONV_TILE_CONV=vendor for A/B timing -- never used for parity claims) the same
-    operations run one by one, in the same order."""
+    never reads them).  Without fusion support (the CPU oracle backend of the tests) and
+    under autograd (training: the library convolution with its own backward, as the
+    reference's nn.Conv2d) the same operations run one by one, in the same order.  On the
+    HIP backend inference never leaves the hand-written kernels: there is no knob that
+    routes it to the vendor library."""
 
     def _native(self, x, prelu=None, live=None, sigmoid=False, gate=None, residual=None, trim=None, ring=0,
                 d2w=None):
         ops = backend.ops()
         slope = prelu.weight if prelu is not None else None
-        vendor = os.environ.get("PCONV_TILE_CONV", "native") == "vendor" or not hasattr(ops, "tile_conv2d")
+        vendor = not hasattr(ops, "tile_conv2d")
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             # training (SURVEY 8f-4): the convolution and its activation go through autograd's library
             # kernels, as the reference's nn.Conv2d does; the tile ops around them use their own backward

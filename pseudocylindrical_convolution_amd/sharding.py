@@ -9,7 +9,8 @@ in the CPU tests): seconds by MAX, everything else by SUM.
 import torch
 import torch.distributed as dist
 
-METRIC_FIELDS = ("pixels", "bits", "frames", "psnr_sum", "ssim_sum")
+# (the last two: seconds per step of bench.py's extra legs -- frames resident in HBM, one frame per call)
+METRIC_FIELDS = ("pixels", "bits", "frames", "psnr_sum", "ssim_sum", "resident_s", "one_frame_s")
 
 
 def shard(total_frames, rank, world):

@@ -69,12 +69,26 @@ def test_wino42_dispatch_rules(hip_backend, monkeypatch):
     assert P().conv3x3_mode() == "wino42"
     for (cfg, want) in (((1, 32, 10, 66, 64), "wino_conv3x3_kernel"), ((1, 96, 5, 66, 128), "conv_mfma_kernel"),
                         ((1, 96, 10, 66, 96), "wino_conv3x3_kernel"), ((1, 96, 10, 66, 128), "wino42_conv3x3_kernel"),
-                        ((1, 192, 10, 66, 192), "wino42_conv3x3_kernel"), ((1, 192, 68, 66, 192), "wino42_conv3x3_kernel"),
-                        ((1, 192, 36, 66, 192), "wino_conv3x3_kernel"), ((1, 192, 20, 66, 192), "wino_conv3x3_kernel")):
+                        ((1, 192, 10, 66, 192), "wino42_conv3x3_kernel"), ((1, 192, 66, 66, 192), "wino42_conv3x3_kernel"),
+                        ((1, 192, 16, 66, 192), "wino_conv3x3_kernel"), ((1, 192, 8, 66, 192), "wino_conv3x3_kernel")):
         x, wt, b, _ = data(*cfg)
         rec.records.clear()
         P().tile_conv2d(type("Owner", (), {})(), x.to(DEV), wt.to(DEV), b.to(DEV), 1)
-        assert rec.records[0][0].split("<")[0] == want, cfg
+        assert [r[0].split("<")[0] for r in rec.records] == [want], cfg
+    # (r6) a remainder of up to four rows behind whole 8-row blocks: the blocks on F(4x2), the remainder on F(2x2)
+    for cfg in ((1, 192, 68, 66, 192), (1, 192, 36, 66, 192), (1, 192, 20, 66, 192), (1, 192, 12, 66, 192), (1, 96, 14, 66, 64)):
+        x, wt, b, _ = data(*cfg)
+        rec.records.clear()
+        P().tile_conv2d(type("Owner", (), {})(), x.to(DEV), wt.to(DEV), b.to(DEV), 1)
+        assert [r[0].split("<")[0] for r in rec.records] == ["wino42_conv3x3_kernel", "wino_conv3x3_kernel"], cfg
+        assert "rows %d of %d" % ((cfg[2] - 2) // 8 * 8, cfg[2] - 2) in rec.records[0][1]
+    monkeypatch.setattr(P(), "WINO_ROW_SPLIT", False)       # the round-5 rule (PCONV_WINO_SPLIT=0)
+    for (cfg, want) in (((1, 192, 68, 66, 192), "wino42_conv3x3_kernel"), ((1, 192, 36, 66, 192), "wino_conv3x3_kernel")):
+        x, wt, b, _ = data(*cfg)
+        rec.records.clear()
+        P().tile_conv2d(type("Owner", (), {})(), x.to(DEV), wt.to(DEV), b.to(DEV), 1)
+        assert [r[0].split("<")[0] for r in rec.records] == [want], cfg
+    monkeypatch.setattr(P(), "WINO_ROW_SPLIT", True)
     monkeypatch.setenv("PCONV_CONV3X3", "wino42!")
     for cfg in ((1, 96, 10, 66, 96), (1, 192, 36, 66, 192)):
         x, wt, b, _ = data(*cfg)
@@ -148,3 +162,38 @@ def test_wino42_relative_error_at_other_scales(xscale, wscale, hip_backend, monk
     rw = ((yw - ref64).abs() / scale).max().item()
     assert rw < 2e-5, "relative error of F(4x2, 3x3): %g" % rw
     assert torch.isfinite(yw).all()
+
+
+@pytest.mark.parametrize("cfg", [(2, 192, 68, 132, 192), (16, 192, 36, 70, 192), (3, 96, 20, 262, 64), (16, 192, 12, 134, 192)])
+def test_row_split_equals_the_direct_kernel(cfg, hip_backend, monkeypatch):
+    """(r6) default dispatch of a layer whose output rows are whole 8-row blocks plus a remainder of two or four rows (66, 34,
+    18, 10): F(4x2) on the blocks, F(2x2) on the remainder, two launches over row views of the same tensors.
+    Against the direct kernel and float64; with residual + trim + PReLU + column limits and with input / residual /
+    output inside padded buffers (the row views then start in the middle of a padded buffer)."""
+    tn, cin, h, w, cout = cfg
+    x, wt, b, sl = data(*cfg, seed=12)
+    ho, wo = h - 2, w - 2
+    res = torch.randn(tn, cout, ho, wo, generator=torch.Generator().manual_seed(13))
+    limit = torch.tensor([wo, 40, 64, 3, 65, 128, wo - 1, 1] * 2, dtype=torch.int32).to(DEV)
+    rec = type("Probe", (), {"records": []})()
+    monkeypatch.setattr(P(), "conv_probe", rec)
+    ref64 = torch.nn.functional.conv2d(x.double(), wt.double(), b.double())
+    y0 = conv(monkeypatch, "wino42", x.to(DEV), wt.to(DEV), b.to(DEV), 1).cpu()
+    assert [r[0] for r in rec.records] == ["wino42_conv3x3_kernel", "wino_conv3x3_kernel"]
+    assert (y0.double() - ref64).abs().max().item() < 3e-5
+
+    def inside(t, p):
+        buf = torch.full((t.shape[0], t.shape[1], t.shape[2] + 2 * p, t.shape[3] + 2 * p), 7.0, device=DEV)
+        buf[:, :, p:-p, p:-p] = t.to(DEV)
+        return buf[:, :, p:-p, p:-p]
+
+    args = (wt.to(DEV), b.to(DEV), 1, sl.to(DEV), limit, 16)
+    for (xin, rin, ring) in ((x.to(DEV), res.to(DEV), 0), (inside(x, 2), inside(res, 2), 2), (inside(x, 1), res.to(DEV), 2)):
+        yd = conv(monkeypatch, "direct", xin, *args, residual=rin, trim=True, ring=ring)
+        rec.records.clear()
+        yw = conv(monkeypatch, "wino42", xin, *args, residual=rin, trim=True, ring=ring)
+        assert [r[0] for r in rec.records] == ["wino42_conv3x3_kernel", "wino_conv3x3_kernel"]
+        assert yw.shape == yd.shape and (yw - yd).abs().max().item() < 3e-5
+        if ring:
+            buf, r = yw._pconv_ring
+            assert buf.shape[2] == ho + 2 * r and torch.equal(buf[:, :, r:-r, r:-r], yw)

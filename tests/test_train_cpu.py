@@ -244,3 +244,52 @@ def test_init_stage_starts_from_the_base_stage_checkpoint(oracle_backend, tmp_pa
     assert _init_stage_job(str(tmp_path), [], port + 2) == []
     log = open(os.path.join(str(tmp_path), "save_models", "ent_normal_16_8_16_init_logs_0.txt")).read()
     assert "base_normal_16_8_16_best_0.pt successful" in log
+
+
+def test_procedural_images_and_packed_weights():
+    """(r6) the procedural training images are deterministic functions of (seed, index) in [0, 1] with real
+    structure (flat shapes: many repeated values; texture: not constant), and the packed checkpoint format keeps
+    small tensors bit for bit and the large ones to fp16 precision"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import weights_pack
+    from pseudocylindrical_convolution_amd.SphereDataset import ProceduralSphereDataSet
+    a, b = ProceduralSphereDataSet(4, 64, 128, seed=3), ProceduralSphereDataSet(4, 64, 128, seed=3)
+    x = a[2]
+    assert x.shape == (3, 64, 128) and x.dtype == torch.float32 and 0.0 <= x.min() and x.max() <= 1.0
+    assert torch.equal(x, b[2]) and not torch.equal(x, a[1]) and not torch.equal(x, ProceduralSphereDataSet(4, 64, 128, seed=4)[2])
+    assert x.std() > 0.02 and set(a.values()) == set(a.img_list) and all(0.5 <= v <= 2.5 for v in a.values().values())
+    state = {"big": torch.randn(300, 300), "small": torch.randn(7), "count": torch.arange(5)}
+    path = os.path.join(ROOT, "gpurun_out", "_pack_test.pt")
+    try:
+        weights_pack.pack(path, {"s": state})
+        back = weights_pack.unpack(path)["s"]
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    assert back["big"].dtype == torch.float32 and torch.equal(back["big"], state["big"].half().float())
+    assert torch.equal(back["small"], state["small"]) and torch.equal(back["count"], state["count"])
+
+
+def test_time_budget_ends_a_base_stage_run_and_keeps_its_checkpoint(oracle_backend, tmp_path):
+    """(r6) --procedural N --time-budget S: a --base run with far more epochs than fit stops at the budget, having
+    tested and saved what it has (the round's real training runs inside 20-minute GPU calls this way)"""
+    import time
+    import torch.distributed as dist
+    from pseudocylindrical_convolution_amd import train
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33000 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
+    args = train.build_parser().parse_args(
+        ["--device", "cpu", "--procedural", "4", "--height", "256", "--width", "512", "--batch-size", "1",
+         "--test-batch-size", "1", "--acc-batch", "1", "--epochs", "100000", "--time-budget", "4", "--valid-dim", "8",
+         "--channels", "16", "--code-dim", "16", "--viewport_size", "24", "--workers", "0", "--no-opt", "--mean", "0",
+         "--base-dir", str(tmp_path), "--base"])
+    t0 = time.time()
+    try:
+        hist = train.Job(0, 1, args)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    assert 1 <= len(hist) < 1000 and time.time() - t0 < 120
+    assert os.path.exists(os.path.join(str(tmp_path), "save_models", "base_normal_16_8_16_best_0.pt"))
+    log = open(os.path.join(str(tmp_path), "save_models", "base_normal_16_8_16_logs_0.txt")).read()
+    assert "time budget" in log

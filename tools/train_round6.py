@@ -42,12 +42,14 @@ def common(args, work):
 
 
 def newest(save_dir, prex):
-    """the later of <prex>_best_0.pt / <prex>_latest.pt (ModuleSaver writes one of them per epoch)"""
-    cands = [os.path.join(save_dir, "%s_%s.pt" % (prex, s)) for s in ("best_0", "latest")]
-    cands = [c for c in cands if os.path.exists(c)]
-    if not cands:
-        raise SystemExit("no checkpoint under %s" % save_dir)
-    return max(cands, key=os.path.getmtime)
+    """the checkpoint with the best test loss (`<prex>_best_0.pt`, ModuleSaver), else `<prex>_latest.pt`.  (Round 6's
+    first stage-1 call returned the LATEST state and with it the loss spike of its last epochs: 31.8 dB at epoch 9,
+    15.5 dB at epoch 10 -- the best one is what a training run hands on.)"""
+    for s in ("best_0", "latest"):
+        cand = os.path.join(save_dir, "%s_%s.pt" % (prex, s))
+        if os.path.exists(cand):
+            return cand
+    raise SystemExit("no checkpoint under %s" % save_dir)
 
 
 def unpack_to(pack_path, name, dst):
