@@ -1241,7 +1241,8 @@ def leaky_clip_(x):
 def frames_u8_to_f32(img, out=None):
     """device side of img2tensor (pseudo_codec.py:215-217): uint8 (n, H, W, 3) GPU tensor -> float32 (n, 3, H, W),
     float(u8) / 255 exactly as the reference's host division; the bus carried a quarter of the bytes"""
-    _require_gpu(img, "frames_u8_to_f32")
+    if not img.is_cuda:
+        raise PconvError("frames_u8_to_f32: expected a GPU tensor (this build has no CPU path), got %s" % img.device)
     if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3 or not img.is_contiguous():
         raise PconvError("frames_u8_to_f32: contiguous uint8 (n, H, W, 3) expected")
     n, h, w, _ = img.shape
@@ -1257,7 +1258,8 @@ def frames_u8_to_f32(img, out=None):
 def frames_f32_to_u8(x, out=None):
     """device side of tensor2img (pseudo_codec.py:219-221): float32 (n, 3, H, W) -> uint8 (n, H, W, 3),
     (uint8)(int)(x * 255) as numpy's cast does it"""
-    _require_gpu(x, "frames_f32_to_u8")
+    if not x.is_cuda:
+        raise PconvError("frames_f32_to_u8: expected a GPU tensor (this build has no CPU path), got %s" % x.device)
     if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
         raise PconvError("frames_f32_to_u8: contiguous float32 (n, 3, H, W) expected")
     n, _, h, w = x.shape

@@ -383,9 +383,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
   float *yimg = y + (size_t)pn * out_img;
   const float *rimg = residual ? residual + (size_t)pn * out_img : nullptr;
   __syncthreads();  // (waits for the DMA: vmcnt(0))
-  int e = first + wave;
-  if (e >= last) return;
+  // contiguous == 2 (r6): the PJ positions a wave takes through the loop body together are NEIGHBOURS on the
+  // anti-diagonal (e, e + 1: 16 of their 25 taps are the same bytes, requested back to back by one wave, so the second
+  // window's lines are in the CU's L1 or in flight); contiguous == 1: e and e + waves (round 3-5: one shared tap).
+  // Which wave evaluates a position changes nothing in its arithmetic.
   const int stride = contiguous ? kWaves : split * kWaves;
+  const int js = contiguous == 2 ? 1 : stride;
+  int e = first + (contiguous == 2 ? wave * PJ : wave);
+  if (e >= last) return;
   // read-only table, wave-uniform index: through the constant address space these are
   // scalar loads (s_load_dwordx4), not a vector load + readfirstlane
   const_i32_t *plist = (const_i32_t *)(g.pos + lo);
@@ -403,13 +408,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
   // trips is PJ times shorter.  Per position the operations and their order are unchanged.
   EePos rec[PJ];
 #pragma unroll
-  for (int j = 0; j < PJ; j++) rec[j] = load_pos(e + j * stride < last ? e + j * stride : e);
+  for (int j = 0; j < PJ; j++) rec[j] = load_pos(e + j * js < last ? e + j * js : e);
 #pragma unroll 1
   for (;;) {
     const int en = e + PJ * stride;
     EePos nxt[PJ];  // requested now, used by the next iteration
 #pragma unroll
-    for (int j = 0; j < PJ; j++) nxt[j] = load_pos(en + j * stride < last ? en + j * stride : e);
+    for (int j = 0; j < PJ; j++) nxt[j] = load_pos(en + j * js < last ? en + j * js : e);
     float xv[PJ][ITER];
     size_t oflat[PJ];
     float r0[PJ], r1[PJ], r2[PJ];  // issued with the gathers: one memory round trip per position
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
     }
 #pragma unroll
     for (int j = 0; j < PJ; j++) {
-      if (j > 0 && e + j * stride >= last) break;  // (uniform) no such position: its lanes computed a copy of e
+      if (j > 0 && e + j * js >= last) break;  // (uniform) no such position: its lanes computed a copy of e
       float v = vsum[j] + (o == 0 ? b0 : (o == 1 ? b1 : b2));
       if (slope) {
         const float sl = o == 0 ? s0 : (o == 1 ? s1 : s2);
@@ -1003,7 +1008,8 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   // PCONV_EE_JOINT: positions a wave takes through the loop body together (1 or 2)
   static const int joint = getenv("PCONV_EE_JOINT") ? atoi(getenv("PCONV_EE_JOINT")) : 2;
   // PCONV_EE_CONTIG: contiguous (1) or interleaved (0) shares of a plane per workgroup
-  static const int contig = getenv("PCONV_EE_CONTIG") ? atoi(getenv("PCONV_EE_CONTIG")) : 1;
+  // (2 = contiguous shares AND the positions of one loop body neighbours on the anti-diagonal: r6)
+  static const int contig = getenv("PCONV_EE_CONTIG") ? atoi(getenv("PCONV_EE_CONTIG")) : 2;
   const int waves = block / kWave;
   int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;

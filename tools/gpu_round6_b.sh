@@ -6,20 +6,21 @@ O=$R/gpurun_out/r6b
 mkdir -p $O
 cd $R
 timeout -k 10 900 python -m pytest tests/test_gpu_frame_io.py tests/test_gpu_wino42.py tests/test_gpu_entropy_mfma.py tests/test_gpu_engine.py -x -q -m gpu 2>&1 | tail -5 | tee $O/tests_new.txt
-echo "--- decode A/B (8 frames = four groups of two; 1 frame)" | tee $O/decode_ab.txt
-for rep in 1 2; do for x in 0 1; do
-  PCONV_EE_XCD=$x timeout -k 10 200 python tools/gpu_probe_decode_modes.py 8 2>&1 | grep decode | tail -2 | sed "s/^/xcd=$x /" | tee -a $O/decode_ab.txt
+echo "--- decode A/B: PCONV_EE_XCD (workgroup order) x PCONV_EE_CONTIG (1 = positions e, e + 4 per loop body; 2 = neighbours e, e + 1)" | tee $O/decode_ab.txt
+for rep in 1 2; do for cfg in "0 1" "1 1" "0 2" "1 2"; do
+  set -- $cfg
+  PCONV_EE_XCD=$1 PCONV_EE_CONTIG=$2 timeout -k 10 200 python tools/gpu_probe_decode_modes.py 8 2>&1 | grep decode | tail -2 | sed "s/^/xcd=$1 contig=$2 /" | tee -a $O/decode_ab.txt
 done; done
-for x in 0 1; do PCONV_EE_XCD=$x timeout -k 10 200 python tools/gpu_probe_decode_modes.py 1 2>&1 | grep decode | tail -2 | sed "s/^/xcd=$x /" | tee -a $O/decode_ab.txt; done
+for cfg in "0 1" "1 2"; do set -- $cfg; PCONV_EE_XCD=$1 PCONV_EE_CONTIG=$2 timeout -k 10 200 python tools/gpu_probe_decode_modes.py 1 2>&1 | grep decode | tail -2 | sed "s/^/xcd=$1 contig=$2 /" | tee -a $O/decode_ab.txt; done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "TC[PC]_[A-Za-z0-9_]*" | sort -u > $O/counters_tcp_tcc.txt
 wc -l $O/counters_tcp_tcc.txt
 i=0
-for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
+for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
   for x in 0 1; do
-    rm -rf /tmp/pmc_$i_$x
-    PCONV_EE_XCD=$x timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_${i}_$x -- python3 $R/tools/gpu_probe_decode_pmc.py 1 > $O/pmc_${i}_$x.out 2> $O/pmc_${i}_$x.err || { echo "pass $i xcd=$x failed"; tail -3 $O/pmc_${i}_$x.err; }
+    rm -rf /tmp/pmc_${i}_$x
+    PCONV_EE_XCD=$x PCONV_EE_CONTIG=$((x+1)) timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_${i}_$x -- python3 $R/tools/gpu_probe_decode_pmc.py 1 > $O/pmc_${i}_$x.out 2> $O/pmc_${i}_$x.err || { echo "pass $i xcd=$x failed"; tail -3 $O/pmc_${i}_$x.err; }
   done
 done
 python3 - <<'PY' | tee $O/step_kernel_pmc.txt
@@ -34,13 +35,13 @@ for x in (0, 1):
                     continue
                 k = "ee_step_kernel<" + k.split("ee_step_kernel<")[1].split(">")[0] + ">"
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print("PCONV_EE_XCD=%d  (one lock-step group of two 4096x2048 frames, per launch averages)" % x)
+    print("PCONV_EE_XCD=%d PCONV_EE_CONTIG=%d  (one lock-step group of two 4096x2048 frames, per launch averages)" % (x, x + 1))
     for k, c in sorted(acc.items()):
         print("  %s" % k)
         for name, v in sorted(c.items()):
             print("    %-34s launches %6d  avg %14.1f" % (name, len(v), sum(v) / len(v)))
 PY
 cd $R
-python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err || tail -20 $O/bench.err
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench.json 2> $O/bench.err || tail -20 $O/bench.err
 cut -c1-1500 $O/bench.json
 echo done

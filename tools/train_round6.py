@@ -117,7 +117,9 @@ def stage2(args):
     t0 = time.time()
     train.main(["--init", "--lr", str(args.lr), "--alpha", "1"] + common(args, work))
     ckpt = newest(save, prex)
-    state = torch.load(ckpt, map_location="cpu")
+    # export.py masks the 5x5 weights with the backend's MaskConstrainOp: on the GPU box the state must live on the GPU
+    # (call 2 of this round loaded it on the CPU and lost a finished stage 2 to "expected a GPU tensor")
+    state = torch.load(ckpt, map_location="cuda:0" if args.device == "cuda" else "cpu")
     codec_dir = os.path.join(work, "codec")
     cprex = "3_%d" % VALID_DIM
     export.export_codec(state, VALID_DIM, codec_dir, cprex)
