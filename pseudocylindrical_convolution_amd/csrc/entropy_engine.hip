@@ -1009,13 +1009,16 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
   static const int joint = getenv("PCONV_EE_JOINT") ? atoi(getenv("PCONV_EE_JOINT")) : 2;
   // PCONV_EE_CONTIG: contiguous (1) or interleaved (0) shares of a plane per workgroup
   // (2 = contiguous shares AND the positions of one loop body neighbours on the anti-diagonal: r6)
-  static const int contig = getenv("PCONV_EE_CONTIG") ? atoi(getenv("PCONV_EE_CONTIG")) : 2;
+  static const int contig = getenv("PCONV_EE_CONTIG") ? atoi(getenv("PCONV_EE_CONTIG")) : 1;
   const int waves = block / kWave;
   int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
   if (split < 1) split = 1;
   const uint32_t *tap = cin == g->ngroup ? g->tap_in : g->tap_hid;
-  // PCONV_EE_XCD: 1 (default) = the 1-D XCD-major workgroup order (see the kernel), 0 = the 3-D grid of rounds 3-5
-  static const int xcd = getenv("PCONV_EE_XCD") ? atoi(getenv("PCONV_EE_XCD")) : 1;
+  // PCONV_EE_XCD: 1 = the 1-D XCD-major workgroup order (see the kernel), 0 (default) = the 3-D grid of rounds 3-5.
+  // Measured (r6, profiles/round6_step_kernel_pmc.txt): XCD-major + neighbour pairs cut the L1 -> L2 requests by a
+  // third and the fabric reads by a sixth, and the decode takes the same time at 8 frames (176-183 vs 176-180 ms) and
+  // LONGER at one frame (95-97 vs 91 ms): the launch is a chain of dependent round trips, not a bandwidth problem.
+  static const int xcd = getenv("PCONV_EE_XCD") ? atoi(getenv("PCONV_EE_XCD")) : 0;
   const long long nb = (long long)split * nplane * 3 * g->nimg;
   PCONV_REQUIRE(3 * g->nimg <= 65535 && nplane <= 65535 && nb < (1LL << 30), "ee_conv: too many images for one launch");
   const dim3 grid = xcd ? dim3((unsigned)(8 * ((nb + 7) / 8)), 1, 1) : dim3((unsigned)split, (unsigned)nplane, (unsigned)(3 * g->nimg));

@@ -44,4 +44,7 @@ PY
 cd $R
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench.json 2> $O/bench.err || tail -20 $O/bench.err
 cut -c1-1500 $O/bench.json
+
+python tools/weights_pack.py unpack trained/r6/codec_3_56.pack.pt /tmp/trained_r6 > /dev/null && python bench.py --steps 5 --warmup 2 --weights /tmp/trained_r6 --content procedural --no-cpu-baseline > $O/bench_trained.json 2> $O/bench_trained.err || tail -20 $O/bench_trained.err
+cut -c1-1500 $O/bench_trained.json
 echo done
