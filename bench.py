@@ -171,6 +171,12 @@ def launch_ranks(nproc, argv, script=None, env=None):
     child_env = dict(os.environ)
     child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     child_env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(nproc, 1))))
+    if "--share-gpu" in argv:
+        # REHEARSAL only (N ranks on ONE GPU): with the frame pipe's copy streams in every process the runtime's default
+        # of 4 hardware queues per process made the queued decoder chains of two processes 2.3 x slower; 8 queues
+        # restore round 5's figures.  One process per GPU -- the deployment -- does not care (measured at 1 / 2 / 4 / 8
+        # frames per call: profiles/round6_rehearsal.txt)
+        child_env.setdefault("GPU_MAX_HW_QUEUES", "8")
     if env:
         child_env.update(env)
     return subprocess.call(cmd, env=child_env)
@@ -451,12 +457,13 @@ class CodecWorkload(object):
             n = min(cap, self.F - lo)
             host = torch.stack([frame_u8(self.H, self.W, 100 + first + (lo + i) * stride, args.content)
                                 for i in range(n)], 0).pin_memory()
-            if n not in self.pipes:
+            if n not in self.pipes and self.io == "host":
                 self.pipes[n] = {"pipe": FramePipe(n, self.H, self.W, dev), "fill": 0, "use": 0}
             # the same frames resident in HBM (io="resident", and the post-run checks): img2tensor of the same bytes
             self.calls.append({"host": host, "n": n, "frames": PCONV.frames_u8_to_f32(host.to(dev)),
                                "streams": None, "rec": None, "host_rec": None, "slot": 0})
-        self._prefetch(0)
+        if self.io == "host":
+            self._prefetch(0)
         self.bits_first, self.bits = None, 0
         self.local = local
 

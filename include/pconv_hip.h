@@ -426,6 +426,10 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
                                       const float *tile_weight, float bias, int nlevels, float total,
                                       float beta);
 void pconv_ee_destroy(pconv_entropy_engine *e);
+/* A non-blocking HIP stream on the current device, created directly (not out of a framework's stream pool): the
+ * copy streams of the frame pipe (host <-> HBM beside the compute).  The caller destroys it. */
+int pconv_stream_create(void **stream);
+int pconv_stream_destroy(void *stream);
 /* layer 0..11 = net.0.conv, net.1.conv1.conv, net.1.conv2.conv, ..., net.6.conv;
  * device pointers: weight (3, 3G, cin, 5, 5), bias (3, 3G), slope (3, 3G) or NULL.
  * The weight is copied (re-packed) on `stream`; bias and slope are borrowed. */

@@ -933,6 +933,22 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
   return e;
 }
 
+// A plain non-blocking HIP stream for the host side of the path (engine.FramePipe's copy streams): created here, not
+// taken from torch's stream pool -- the first stream a process takes from that pool creates the pool's 32 + 32
+// streams, and two ranks that share a GPU then lost a quarter of their throughput (r6, profiles/round6_rehearsal.txt).
+int pconv_stream_create(void **stream) {
+  PCONV_REQUIRE(stream, "stream_create: null pointer");
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void *)s;
+  return PCONV_OK;
+}
+
+int pconv_stream_destroy(void *stream) {
+  if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return PCONV_OK;
+}
+
 void pconv_ee_destroy(pconv_entropy_engine *e) {
   if (!e) return;
   if (e->enc_thread.joinable()) e->enc_thread.join();

@@ -387,7 +387,14 @@ class FramePipe(object):
         if not hasattr(self.ops, "frames_u8_to_f32"):
             raise PconvError("FramePipe needs the HIP backend")
         shape = (self.n, self.h, self.w, 3)
-        self.up, self.down = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        # one copy stream per direction, created through the C ABI (pconv_stream_create) rather than taken from
+        # torch's pool (whose first use creates 64 streams in the process).  NOTE for processes that SHARE one GPU
+        # (bench.py --share-gpu, never a deployment): the HIP runtime multiplexes a process's streams onto 4 hardware
+        # queues by default, and with these two streams more the engine's queued decoder chains of two such processes
+        # ran 2.3 x slower (2 ranks x 4 frames: 70 instead of 94 MPix/s) until GPU_MAX_HW_QUEUES=8 was exported; one
+        # process per GPU is indifferent to the knob at 1 / 2 / 4 / 8 frames per call (profiles/round6_rehearsal.txt)
+        self._raw = []
+        self.up, self.down = self._stream(), self._stream()
         self.dev_in = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.dev_out = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.host_out = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -395,6 +402,13 @@ class FramePipe(object):
         ev = lambda: [torch.cuda.Event() for _ in range(2)]
         self.up_done, self.in_free, self.out_ready, self.down_done = ev(), ev(), ev(), ev()
         self._in_used, self._out_used = [False, False], [False, False]
+
+    def _stream(self):
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            call("pconv_stream_create", ctypes.byref(handle))
+        self._raw.append(handle)   # (lives as long as the process: a pipe is created once per workload)
+        return torch.cuda.ExternalStream(handle.value, device=self.device)
 
     def prefetch(self, host_u8, slot):
         """queue the upload of a batch (pinned uint8 (n, H, W, 3)) into input slot `slot` on the upload stream"""

@@ -29,21 +29,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def perturb_transforms(module, seed):
-    """move every parameter family of the transforms away from its initial value, deterministically"""
+    """move every parameter family of the transforms away from its initial value, deterministically
+    (random numbers from a CPU generator whatever device the parameters live on: the same draw on both backends)"""
     g = torch.Generator().manual_seed(1000 + seed)
+
+    def rand(shape):
+        return torch.rand(shape, generator=g)
+
     with torch.no_grad():
         for name, p in module.named_parameters():
             leaf = name.rsplit(".", 1)[-1]
             if leaf == "beta":                                    # GDN: stored as sqrt(beta + pedestal)
-                p.mul_(0.7 + 0.8 * torch.rand(p.shape, generator=g))
+                p.mul_((0.7 + 0.8 * rand(p.shape)).to(p.device))
             elif leaf == "gamma":
-                p.add_(0.05 * torch.rand(p.shape, generator=g))
+                p.add_((0.05 * rand(p.shape)).to(p.device))
             elif p.dim() == 1 and "conv" not in name and p.numel() <= 768 and leaf == "weight":
-                p.copy_(0.05 + 0.45 * torch.rand(p.shape, generator=g))   # PReLU slopes
+                p.copy_((0.05 + 0.45 * rand(p.shape)).to(p.device))   # PReLU slopes
             elif p.dim() == 4:
-                p.mul_(0.8 + 0.5 * float(torch.rand(1, generator=g)))
+                p.mul_(0.8 + 0.5 * float(rand(1)))
             elif leaf == "bias":
-                p.add_(0.02 * torch.randn(p.shape, generator=g))
+                p.add_((0.02 * torch.randn(p.shape, generator=g)).to(p.device))
 
 
 def sharp_entropy_state(ent, seed=5):
@@ -71,7 +76,7 @@ def build_codec(tseed, ent_state_fn):
     g = torch.Generator().manual_seed(2000 + tseed)
     with torch.no_grad():
         # quantiser levels: sorted, uneven spacing (pseudo_quant_cuda.cu:15-35 reads them as increments)
-        enc.quant.weight.mul_(0.6 + 0.8 * torch.rand(enc.quant.weight.shape, generator=g))
+        enc.quant.weight.mul_((0.6 + 0.8 * torch.rand(enc.quant.weight.shape, generator=g)).to(enc.quant.weight.device))
         dec.quant.weight.data.copy_(enc.quant.weight.data)
     sd = ent_state_fn(enc.ent)
     enc.ent.load_state_dict(sd)
