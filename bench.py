@@ -57,7 +57,7 @@ def winograd_gain(kernel):
             return gain
     return 1.0
 MODEL_VALID_DIM = 56                 # model-idx 3 of the --ssim list (pseudo_codec.py:18-19)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("round5_bench_pmc.json", "round4_bench_pmc.json", "round3_bench_pmc.json",
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("round6_bench_pmc.json", "round5_bench_pmc.json", "round4_bench_pmc.json", "round3_bench_pmc.json",
                                                              "round2_bench_pmc.json")]
 
 
@@ -651,6 +651,17 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
 
     if on_gpu and os.environ.get("PCONV_BENCH_CU_MASK"):
         torch.cuda.set_stream(cu_masked_stream(os.environ["PCONV_BENCH_CU_MASK"], local_dev))
+    device_flag = None
+    if on_gpu and workload_cls is None:
+        # a rank with fewer CPUs than its call has threads asks, explicitly, for sleeping runtime waits on its device
+        # (the engine's own waits are blocking events either way) and reports whether the runtime took the flag
+        import ctypes
+        from pseudocylindrical_convolution_amd import _native
+        lib = _native.hip_lib()
+        plan = [ctypes.c_int(0) for _ in range(4)]
+        if lib.pconv_ee_host_plan(min(args.frames_per_gpu, args.max_frames_per_call), *[ctypes.addressof(v) for v in plan]) == 0 \
+                and plan[3].value:
+            device_flag = lib.pconv_device_blocking_sync(1) == 1
     load = (workload_cls or WORKLOADS[args.mode])(args, rank, local_dev, dev)
 
     def fence():
@@ -779,7 +790,10 @@ def run(args, workload_cls=None, dist_backend="nccl", device_type="cuda"):
         if getattr(load, "codec", None) is not None and on_gpu:
             eng = load.codec._engine("dec", 2 * (load.H // 256), 2 * (load.W // 16), load.calls[0]["n"])
             lib = eng.lib
-            config["host_waits"] = "sleeping (blocking events)" if lib.pconv_ee_wait_mode(eng.handle) == 1 else "spinning (runtime default)"
+            config["host_waits"] = "spinning (runtime default)"
+            if lib.pconv_ee_wait_mode(eng.handle) == 1:
+                config["host_waits"] = "sleeping (engine: blocking events; device flag hipDeviceScheduleBlockingSync: %s)" % (
+                    "in effect, read back" if device_flag else ("refused by the runtime" if device_flag is False else "not asked for"))
         if strong:
             config["frames_total"] = args.frames_total
         if emulate:

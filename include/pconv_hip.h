@@ -457,6 +457,11 @@ int pconv_ee_host_plan(int nimg, int *groups, int *group_threads, int *queued_ch
  * waits on blocking events (hipEventBlockingSync; the plan's blocking_sync, fixed at pconv_ee_create).  No device-wide
  * schedule flag is set either way. */
 int pconv_ee_wait_mode(const pconv_entropy_engine *e);
+/* Explicit, process-wide opt-in: hipSetDeviceFlags(hipDeviceScheduleBlockingSync) on the current device (enable != 0),
+ * then the flag is read back: returns 1 when every runtime wait on the device now sleeps, 0 when it does not (not asked
+ * for, or refused by the runtime on a live context -- the engine's blocking events still apply then).  Never called by
+ * the library itself. */
+int pconv_device_blocking_sync(int enable);
 /* symbols: device float (nimg*npart, ngroup, h, w), dead columns zero */
 int pconv_ee_encode(pconv_entropy_engine *e, const float *symbols, void *stream);
 /* the same in two halves: begin queues the GPU part IN `stream` and starts the host thread that

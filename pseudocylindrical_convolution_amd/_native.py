@@ -87,6 +87,7 @@ _HIP_SIGNATURES = {
     "pconv_ee_spin_us": [I],
     "pconv_ee_host_plan": [I, P, P, P, P],
     "pconv_ee_wait_mode": [P],
+    "pconv_device_blocking_sync": [I],
     "pconv_stream_create": [P],
     "pconv_stream_destroy": [P],
     "pconv_ee_encode": [P, P, P],

@@ -265,6 +265,7 @@ def test_host_constrained_plan_decodes_the_same_symbols(hip_backend, monkeypatch
     assert lib.pconv_ee_wait_mode(tight.handle) == 1
     assert torch.equal(tight.decode(streams), sym)
     assert lib.pconv_ee_wait_mode(roomy.handle) == 0
+    assert lib.pconv_device_blocking_sync(0) in (0, 1)       # (a query: the explicit opt-in itself is the application's call)
     # one CPU: a single group, one thread
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
     one = EntropyEngine(ent, h, w, n, "cuda:0")
