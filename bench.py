@@ -567,8 +567,8 @@ WORKLOADS = {"codec": CodecWorkload, "analysis": AnalysisWorkload}
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=sorted(WORKLOADS), default="codec")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
