@@ -711,8 +711,11 @@ class PseudoQuantOp(_Op):
         # reference hands it to autograd as the "gradient" of the module's `count`
         self.count_data_ = self._out("count", (c, self.bin_num_), x)
         self.count_data_.zero_()
+        # (r6) the histogram has one reader, the training graph (backward hands it to `count` as its "gradient"): an
+        # eval-mode call under no_grad -- the codec -- leaves it zero and takes the kernel's 16-byte form
+        hist = self.count_data_ if (train or torch.is_grad_enabled()) else None
         with _HbmTimed("quant_kernel", "PseudoQuant c%d w%d" % (x.shape[1], x.shape[3]), 12.0 * x.numel(), x.device):
-            call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), _ptr(self.count_data_),
+            call("pconv_quant", _ptr(x), _ptr(weight.detach()), _ptr(tab), _ptr(val), _ptr(idx), _ptr(hist),
                  _ptr(wd), tn, c, h, w, self.bin_num_, self.npart_, _stream(x.device))
         if train:
             self.iter_ += 1

@@ -86,6 +86,98 @@ __global__ __launch_bounds__(kBlock) void quant_kernel(
   }
 }
 
+// The same quantiser for the codec's shape -- 8 levels, no histogram (eval mode), rows of a multiple of 4 columns --
+// with 16-byte accesses (r6): a thread owns 4 consecutive columns of one (tile, channel, row), loads the channel's 8
+// level increments ONCE as two 16-byte pieces (the scalar kernel walked them through up to 8 dependent loads per
+// element) and runs, per element, the very operations of quant_kernel in the same order: identical bits.
+__device__ __forceinline__ void quant8_one(float v, const float (&lv)[8], float &val, float &idx) {
+  float tmp = v - lv[0];
+  if (tmp < 0) {
+    val = lv[0];
+    idx = 0.f;
+    return;
+  }
+  int j = 8;
+  bool brk = false;
+#pragma unroll
+  for (int k = 1; k < 8; k++) {
+    if (!brk) {
+      tmp -= lv[k];
+      if (tmp < 0) {
+        brk = true;
+        j = k;
+      }
+    }
+  }
+  if (!brk) j = 7;
+  float lvj = lv[1];
+#pragma unroll
+  for (int k = 2; k < 8; k++) lvj = j == k ? lv[k] : lvj;
+  if (tmp + tmp + lvj < 0) {
+    tmp = tmp + lvj;
+    j--;
+  }
+  val = v - tmp;
+  idx = (float)j;
+}
+
+__global__ __launch_bounds__(kBlock) void quant8x4_kernel(const float4 *__restrict__ x, const float *__restrict__ tab,
+                                                         float4 *__restrict__ out_val, float4 *__restrict__ out_idx,
+                                                         const int32_t *__restrict__ widths, int c, int hw, int w,
+                                                         int npart, long long total4) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (long long)gridDim.x * kBlock) {
+    const long long e = 4 * i;
+    const int pw = (int)(e % w);
+    const long long plane = e / hw;
+    const int pc = (int)(plane % c);
+    const int pg = (int)((plane / c) % npart);
+    const int live = widths[pg] - pw;  // columns of this quad inside the tile's valid width
+    float4 val = {0.f, 0.f, 0.f, 0.f}, idx = {0.f, 0.f, 0.f, 0.f};
+    if (live > 0) {
+      const float4 t0 = *reinterpret_cast<const float4 *>(tab + pc * 8), t1 = *reinterpret_cast<const float4 *>(tab + pc * 8 + 4);
+      const float lv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      const float4 v = x[i];
+      quant8_one(v.x, lv, val.x, idx.x);
+      if (live > 1) quant8_one(v.y, lv, val.y, idx.y);
+      if (live > 2) quant8_one(v.z, lv, val.z, idx.z);
+      if (live > 3) quant8_one(v.w, lv, val.w, idx.w);
+    }
+    out_val[i] = val;
+    if (out_idx) out_idx[i] = idx;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void dquant8x4_kernel(const float4 *__restrict__ x, const float *__restrict__ tab,
+                                                          float4 *__restrict__ out, const int32_t *__restrict__ widths,
+                                                          int c, int hw, int w, int npart, long long total4) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (long long)gridDim.x * kBlock) {
+    const long long e = 4 * i;
+    const int pw = (int)(e % w);
+    const long long plane = e / hw;
+    const int pc = (int)(plane % c);
+    const int pg = (int)((plane / c) % npart);
+    const int live = widths[pg] - pw;
+    float4 o = {0.f, 0.f, 0.f, 0.f};
+    if (live > 0) {
+      const float4 t0 = *reinterpret_cast<const float4 *>(tab + pc * 8), t1 = *reinterpret_cast<const float4 *>(tab + pc * 8 + 4);
+      const float lv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      const float4 v = x[i];
+      auto look = [&](float s) {
+        const int k = static_cast<int>(s + 0.00001);
+        float r = lv[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) r = k == q ? lv[q] : r;
+        return r;
+      };
+      o.x = look(v.x);
+      if (live > 1) o.y = look(v.y);
+      if (live > 2) o.z = look(v.z);
+      if (live > 3) o.w = look(v.w);
+    }
+    out[i] = o;
+  }
+}
+
 // pseudo_dquant_cuda.cu:34-47
 __global__ __launch_bounds__(kBlock) void dquant_kernel(const float *__restrict__ x,
                                                         const float *__restrict__ tab,
@@ -347,8 +439,16 @@ extern "C" int pconv_quant(const float *x, const float *weight, float *level_tab
   hipLaunchKernelGGL(quant_levels_kernel, dim3((ntab + 255) / 256), dim3(256), 0,
                      as_stream(stream), weight, level_tab, ntab, levels);
   const long long total = (long long)tn * c * h * w;
-  hipLaunchKernelGGL(quant_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x,
-                     level_tab, out_val, out_idx, count, widths, c, h * w, w, levels, npart, total);
+  const bool quads = levels == 8 && !count && (w & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out_val) |
+                       reinterpret_cast<uintptr_t>(out_idx) | reinterpret_cast<uintptr_t>(level_tab)) & 15) == 0;
+  if (quads)
+    hipLaunchKernelGGL(quant8x4_kernel, dim3(pconv_grid(total / 4)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), level_tab, reinterpret_cast<float4 *>(out_val),
+                       reinterpret_cast<float4 *>(out_idx), widths, c, h * w, w, npart, total / 4);
+  else
+    hipLaunchKernelGGL(quant_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x,
+                       level_tab, out_val, out_idx, count, widths, c, h * w, w, levels, npart, total);
   PCONV_LAUNCH_CHECK("quant");
   return PCONV_OK;
 }
@@ -361,8 +461,16 @@ extern "C" int pconv_dquant(const float *x, const float *weight, float *level_ta
   hipLaunchKernelGGL(dquant_levels_kernel, dim3((wc + 255) / 256), dim3(256), 0, as_stream(stream),
                      weight, level_tab, wc, levels);
   const long long total = (long long)tn * c * h * w;
-  hipLaunchKernelGGL(dquant_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x,
-                     level_tab, out, widths, c, h * w, w, levels, npart, total);
+  const bool quads = levels == 8 && (w & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                       reinterpret_cast<uintptr_t>(level_tab)) & 15) == 0;
+  if (quads)
+    hipLaunchKernelGGL(dquant8x4_kernel, dim3(pconv_grid(total / 4)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), level_tab, reinterpret_cast<float4 *>(out), widths, c, h * w,
+                       w, npart, total / 4);
+  else
+    hipLaunchKernelGGL(dquant_kernel, dim3(pconv_grid(total)), dim3(kBlock), 0, as_stream(stream), x,
+                       level_tab, out, widths, c, h * w, w, levels, npart, total);
   PCONV_LAUNCH_CHECK("dquant");
   return PCONV_OK;
 }

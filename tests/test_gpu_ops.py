@@ -148,6 +148,38 @@ def test_quant_dquant():
     same(gd, cd)
 
 
+def test_quant_dquant_sixteen_byte_forms():
+    """(r6) eval mode under no_grad -- the codec's call -- takes the kernels' 16-byte forms (8 levels, 4 columns per
+    thread, the channel's levels in registers): same values and indices as the oracle, ragged tile widths (the valid
+    width of a tile ends inside a quad), values on and beyond the outermost levels; the per-call histogram stays zero"""
+    x = rnd(32, 192, 4, 128, seed=21) * 1.5
+    x[0, 0, 0, :8] = torch.tensor([-5.0, 5.0, 0.0, 1. / 9, 2. / 9, 0.5, 0.999, 1.0])
+    weight = torch.zeros(192, 8)
+    weight[:, 0] = 1. / 9
+    weight[:, 1:] = float(np.log(1. / 9))
+    weight += rnd(192, 8, seed=22) * 0.2
+    count = torch.zeros(192, 8)
+    gctx = P().PseudoContextOp(16, 20, W16, 0, False)
+    octx = O.PseudoContextOp(16, 20, W16)
+    gop = P().PseudoQuantOp(192, 8, 16, 0.9, 100, 2, 0.1, gctx.addr(), 0, False)
+    with torch.no_grad():
+        gv, gi = gop.forward(x.to(DEV), weight.to(DEV), count.to(DEV), False)
+        assert float(gop.count_data_.abs().sum()) == 0.0
+        cv, ci = O.PseudoQuantOp(192, 8, 16, 0.9, 100, 2, 0.1, octx.addr()).forward(x, weight, count, False)
+        same(gi, ci)
+        same(gv, cv)
+        assert set(ci.unique().tolist()) == set(float(k) for k in range(8))
+        sub = ci[:, :56].contiguous()
+        gd = P().PseudoDQuantOp(16, 192, 8, gctx.addr(), 0, False).forward(sub.to(DEV), weight.to(DEV))[0]
+        cd = O.PseudoDQuantOp(16, 192, 8, octx.addr()).forward(sub, weight)[0]
+        same(gd, cd)
+    # ... and with gradients enabled the scalar form with the histogram, same values
+    gv2, gi2 = gop.forward(x.to(DEV), weight.to(DEV), count.to(DEV), False)
+    same(gi2, ci)
+    same(gv2, cv)
+    assert float(gop.count_data_.sum()) < 0.0
+
+
 def test_projects():
     x = rnd(1, 3, 512, 1024, seed=9)
     th = [-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0]
