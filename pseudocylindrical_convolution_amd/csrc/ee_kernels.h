@@ -107,6 +107,13 @@ int ee_tables_bulk(const EeGeom *g, const float *y_last, const float *symbols, i
                    int nstep, float bias, float total, float beta, int first_idx, int n_idx, int s_lo, int s_hi,
                    int packed, void *stream);
 
+// decoder (r6): the LAST layer of a step (no activation, no residual, unpadded output nobody else reads) and the packed
+// CDF rows of its positions in one launch; x = the last layer's input (3*ngroup channels, padded by 2), rows as
+// ee_tables(packed) writes them.  The codec's shape only: 14 groups, 8 symbols, total 65536.
+int ee_conv_tables(const EeGeom *g, const float *x, const float *packed_w, const float *bias, int32_t *table, int cin,
+                   int first_plane, int nplane, int longest_plane, int psum, int lo, int len, float gbias, float total,
+                   float beta, int32_t *counter, int32_t *flags, int publish, void *stream);
+
 // halos and wrap columns of a whole buffer of `nrep` images with C channels from
 // its interior (bulk mode, after a layer has been evaluated everywhere)
 int ee_halo_bulk(const EeGeom *g, float *buf, int C, int nrep, void *stream);

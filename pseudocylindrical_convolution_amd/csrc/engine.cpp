@@ -312,6 +312,7 @@ struct pconv_entropy_engine {
   float *vh_wgt = nullptr;
   int32_t *pos_plane_d = nullptr;
   HostPlan plan;                  // the host side of this engine's calls, decided ONCE (pconv_ee_create)
+  bool fuse_tables = false;       // decoder: last layer + table kernel as one launch (PCONV_EE_FUSE_TABLES, at creation)
   bool stepwise_encoder = false;  // debugging aid: encode step by step like the decoder
   int encode_ranges = -1;         // step ranges of a call's last group (pconv_ee_set_encode_ranges); -1: the default
   float *lw[kLayers] = {nullptr};  // engine-owned packed weights
@@ -663,10 +664,10 @@ struct pconv_entropy_engine {
 
   // the 12 layers of one wavefront step (EntropyConvDBT / EntropyResidualBlockDBT
   // of pseudo_codec.py:27-51, 79-87)
-  int network_step(Group &g, int s, const Window &cur) {
+  int network_step(Group &g, int s, const Window &cur, int nlayers = kLayers) {
     if (cur.len <= 0) return PCONV_OK;
     const int hid = 3 * ngroup;
-    for (int l = 0; l < kLayers; l++) {
+    for (int l = 0; l < nlayers; l++) {
       const float *in = (l == 0) ? g.ctx : g.act[l - 1];
       // second conv of a residual block: += block input, folded into the epilogue
       const float *res = (l >= 2 && l <= 10 && (l % 2) == 0) ? g.act[l - 2] : nullptr;
@@ -826,9 +827,19 @@ struct pconv_entropy_engine {
     if (s > 0)
       PC_TRY(ee_scatter(&g.geom, g.packed_h, g.ctx, prev.lo, prev.len, s - 1, -bias, flags, g.counter_d + 8, s, g.stream));
     if (cur.len > 0) {
-      PC_TRY(network_step(g, s, cur));
-      PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_h, nullptr, cur.lo, cur.len, s, nlevels, bias,
-                       total, beta, g.counter_d, flags, s + 1, packed, g.stream));
+      // PCONV_EE_FUSE_TABLES=1 (read when the engine is created): the last layer and the table kernel as one launch
+      // (ee_conv_tables; the codec's shape with packed rows only).  Identical rows -- and 2-8 % SLOWER decodes
+      // (profiles/round6_fused_tables.txt): off by default
+      if (fuse_tables && packed && ngroup == 14 && nlevels == 8 && total == 65536.f) {
+        PC_TRY(network_step(g, s, cur, kLayers - 1));
+        PC_TRY(ee_conv_tables(&g.geom, g.act[kLayers - 2], lw[kLayers - 1], lb[kLayers - 1], g.tables_h,
+                              layer_cin(kLayers - 1), cur.first, cur.nplane, longest_plane, s, cur.lo, cur.len, bias, total,
+                              beta, g.counter_d, flags, s + 1, g.stream));
+      } else {
+        PC_TRY(network_step(g, s, cur));
+        PC_TRY(ee_tables(&g.geom, g.act[kLayers - 1], nullptr, g.tables_h, nullptr, cur.lo, cur.len, s, nlevels, bias,
+                         total, beta, g.counter_d, flags, s + 1, packed, g.stream));
+      }
     }
     return PCONV_OK;
   }
@@ -923,6 +934,7 @@ pconv_entropy_engine *pconv_ee_create(int npart, int ngroup, int h, int w, int n
   // is decided here, once, from the rank's share of the host as it is NOW; decode reuses it (a changed affinity
   // mask or LOCAL_WORLD_SIZE between create and decode cannot disagree with the groups that exist).
   e->plan = host_plan(nimg);
+  if (const char *env = getenv("PCONV_EE_FUSE_TABLES")) e->fuse_tables = atoi(env) != 0;
   e->npart = npart; e->ngroup = ngroup; e->h = h; e->w = w; e->nimg = nimg;
   e->bias = bias; e->nlevels = nlevels; e->total = total; e->beta = beta;
   if (e->init(tile_weight) != PCONV_OK) {

@@ -530,6 +530,164 @@ __global__ __launch_bounds__(BLOCK, BLOCK > 512 ? 4 : (ITER * PJ <= 20 ? 8 : (IT
   }
 }
 
+// Decoder, LAST layer of a step and the CDF rows of its positions in ONE launch (r6): the last
+// layer has no activation, no residual and no padded output -- its 3 x 3 values per (position, group) are read by
+// the table kernel only.  A workgroup is (part, plane, image) and owns ALL THREE weight sets of its positions (three
+// slabs in LDS): a wave takes two neighbouring positions through the three sets one after the other -- per (position,
+// set) the very gathers, packed fmaf chains and butterfly of ee_step_kernel<CIN, ITER, BLOCK, 2> -- then the nine
+// parameters of a position sit in the wave (a row of 16 lanes per output, identical in its lanes: three v_readlane per
+// set), lanes 0-7 / 8-15 evaluate the 8 CDF entries of the first / second position with ee_tables8_kernel's
+// operations (same device functions, same repair), and the octet's first lane stores the packed 16-byte row.  One
+// launch boundary and one latency-bound kernel less per step; identical rows by construction.
+template <int CIN, int ITER, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void ee_step_tables_kernel(
+    EeGeom g, const float *__restrict__ x, const float *__restrict__ wp, const uint32_t *__restrict__ tapoff,
+    const float *__restrict__ bias, int32_t *__restrict__ table, int first_plane, int psum, int win_lo, int win_len,
+    float gbias, float total, float beta, int32_t *counter, volatile int32_t *flags, int publish) {
+  constexpr int kWaves = BLOCK / kWave;
+  constexpr int SLOTS = ITER * kWave;
+  constexpr int NS = 8;
+  static_assert(SLOTS == slab_slots(CIN), "ITER must cover the padded reduction length");
+  const int part = blockIdx.x, split = gridDim.x;
+  const int plane = first_plane + blockIdx.y;
+  const int img = blockIdx.z;
+  typedef const __attribute__((address_space(4))) int32_t const_i32_t;
+  const_i32_t *pstart = (const_i32_t *)g.plane_start;
+  const int lo = pstart[plane];
+  const int cnt = pstart[plane + 1] - lo;
+  const int share = (cnt + split - 1) / split;
+  const int first = part * share;
+  const int last = first + share < cnt ? first + share : cnt;
+  const bool active = first < cnt;  // (uniform; an idle workgroup still counts itself in at the end)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int tc = psum - plane;
+  const int cout = GO * g.ngroup;
+  const int h = g.h, w = g.w;
+  const int win = w + 2 * PAD;
+  __shared__ __attribute__((aligned(16))) float4 lw[3][SLOTS];
+  __shared__ unsigned toff[SLOTS];
+  if (active) {
+    typedef __attribute__((address_space(3))) void lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void glb_ptr_t;
+#pragma unroll
+    for (int set = 0; set < 3; set++) {
+      const float4 *slab = reinterpret_cast<const float4 *>(wp + ((size_t)set * g.ngroup + tc) * slab_floats(CIN));
+      for (int i = wave; i < ITER; i += kWaves)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t *)(slab + i * kWave + lane), (lds_ptr_t *)(&lw[set][i * kWave]), 16, 0, 0);
+    }
+    for (int i = wave; i < ITER; i += kWaves)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t *)(tapoff + i * kWave + lane), (lds_ptr_t *)(toff + i * kWave), 4, 0, 0);
+  }
+  const int row = lane >> 4;
+  const int o = row == 0 ? 0 : (row == 2 ? 1 : 2);
+  float bo[3];
+#pragma unroll
+  for (int set = 0; set < 3; set++) bo[set] = bias[set * cout + tc * GO + o];
+  const size_t in_img = (size_t)g.npart * (h + 2 * PAD) * win * CIN;
+  __syncthreads();  // (waits for the DMA: vmcnt(0))
+  if (active) {
+    const_i32_t *plist = (const_i32_t *)(g.pos + lo);
+    for (int e = first + wave * 2; e < last; e += 2 * kWaves) {
+      const bool second = e + 1 < last;  // (uniform)
+      const int e1 = second ? e + 1 : e;
+      const int pix0 = plist[4 * e], pix1 = plist[4 * e1];
+      float val[3][2];
+#pragma unroll
+      for (int set = 0; set < 3; set++) {
+        const float *ximg = x + (size_t)(set * g.nimg + img) * in_img;
+        const float *xin0 = ximg + (size_t)pix0 * CIN, *xin1 = ximg + (size_t)pix1 * CIN;
+        float xv[2][ITER];
+        int tl = lane;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+          unsigned off = toff[tl + it * kWave];
+          asm volatile("" : "+v"(off));
+          xv[0][it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin0) + off);
+          xv[1][it] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xin1) + off);
+        }
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+          const float4 wv = lw[set][lane + it * kWave];
+          asm volatile("" ::"v"(wv.w));
+          const f2 xx = {xv[0][it], xv[1][it]};
+          p0 = __builtin_elementwise_fma(xx, (f2){wv.x, wv.x}, p0);
+          p1 = __builtin_elementwise_fma(xx, (f2){wv.y, wv.y}, p1);
+          p2 = __builtin_elementwise_fma(xx, (f2){wv.z, wv.z}, p2);
+          if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        float s0 = butterfly3(p0.x, p1.x, p2.x), s1 = butterfly3(p0.y, p1.y, p2.y);
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        val[set][0] = s0 + bo[set];
+        val[set][1] = s1 + bo[set];
+      }
+      // the nine parameters of each position: output k of a set sits in the lanes of row {0, 2, 1}[k]
+      const int pj = (lane >> 3) & 1;
+      float par[3][3];
+#pragma unroll
+      for (int set = 0; set < 3; set++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int src = k == 0 ? 0 : (k == 1 ? 32 : 16);
+          const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val[set][0]), src));
+          const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val[set][1]), src));
+          par[set][k] = pj ? b : a;
+        }
+      }
+      const int q = lane & 7;
+      const bool have = lane < 16 && (pj == 0 || second);
+      gmm_prepare_row(par[0], par[1], 3, beta);
+      float cur = gmm_cdf_entry(par[0], par[1], par[2], 3, NS, q + 1, gbias, total);
+      float raw[NS];
+      const int base_lane = lane & ~7;
+#pragma unroll
+      for (int i = 0; i < NS; i++) raw[i] = __shfl(cur, base_lane + i, 64);
+      {
+        // check kernel (entropy_gmm_table_cuda.cu:83-105), as ee_tables8_kernel
+        float prev = 0.f, shift = 0.f, widest = 0.f, mine = 0.f;
+        int widest_at = 0;
+#pragma unroll
+        for (int pt = 1; pt <= NS; pt++) {
+          float c = raw[pt - 1];
+          if (c <= prev) shift += 1;
+          c += shift;
+          if (c - prev > widest) {
+            widest = c - prev;
+            widest_at = pt - 1;
+          }
+          if (pt == q + 1) mine = c;
+          prev = c;
+        }
+        if (shift > 0 && q >= widest_at) mine = (float)(int32_t)mine - shift;
+        cur = mine;
+      }
+      int32_t rowv[NS + 1];
+      rowv[0] = 0;
+#pragma unroll
+      for (int i = 0; i < NS; i++) rowv[i + 1] = (int32_t)__shfl(cur, base_lane + i, 64);
+      if (have && q == 0) {
+        const int l = lo + e + pj - win_lo;  // row of this position in the step's window
+        reinterpret_cast<uint4 *>(table)[(size_t)img * win_len + l] = pack_row16(rowv, 0);
+      }
+    }
+  }
+  if (flags) {
+    __syncthreads();  // every wave of the block has drained its stores (vmcnt(0) before the barrier)
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+      if (atomicAdd(counter, 1) == nblocks - 1) {
+        *counter = 0;  // ready for the next step of this stream
+        __threadfence_system();
+        __hip_atomic_store(const_cast<int32_t *>(flags) + 1, publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 // Encoder ("bulk") form of the same layer: every symbol is known, so a position
 // can be evaluated for ALL its channel groups at once.  A wave owns PP positions:
 // it gathers their 5 x 5 x CIN windows a single time, then walks the groups -- the
@@ -1060,6 +1218,25 @@ int ee_conv(const EeGeom *g, const float *x, int shared_input, const float *pack
 #undef EE_LAUNCH_B
 #undef EE_LAUNCH_J
   PCONV_LAUNCH_CHECK("ee_conv");
+  return PCONV_OK;
+}
+
+int ee_conv_tables(const EeGeom *g, const float *x, const float *packed_w, const float *bias, int32_t *table, int cin,
+                   int first_plane, int nplane, int longest_plane, int psum, int lo, int len, float gbias, float total,
+                   float beta, int32_t *counter, int32_t *flags, int publish, void *stream) {
+  if (nplane <= 0 || longest_plane <= 0 || len <= 0) return PCONV_OK;
+  PCONV_REQUIRE(cin == 42 && g->ngroup == 14 && total == 65536.f, "ee_conv_tables: the codec's shape only (14 groups, 8 x 65536 rows)");
+  // positions a wave takes: two per loop body; PCONV_EE_FUSE_PPW positions per wave (default 4: two bodies)
+  static const int ppw = getenv("PCONV_EE_FUSE_PPW") ? atoi(getenv("PCONV_EE_FUSE_PPW")) : 4;
+  const int waves = kConvBlock / kWave;
+  int split = (longest_plane + waves * ppw - 1) / (waves * ppw);
+  if (split < 1) split = 1;
+  PCONV_REQUIRE(g->nimg <= 65535 && nplane <= 65535, "ee_conv_tables: too many images for one launch");
+  const dim3 grid((unsigned)split, (unsigned)nplane, (unsigned)g->nimg);
+  hipLaunchKernelGGL((ee_step_tables_kernel<42, 17, kConvBlock>), grid, dim3(kConvBlock), 0, as_stream(stream), *g, x, packed_w,
+                     g->tap_hid, bias, table, first_plane, psum, lo, len, gbias, total, beta, counter,
+                     (volatile int32_t *)flags, publish);
+  PCONV_LAUNCH_CHECK("ee_conv_tables");
   return PCONV_OK;
 }
 

@@ -284,7 +284,8 @@ def test_engine_knobs_that_must_not_change_a_stream(hip_backend, monkeypatch):
     sym = torch.randint(0, 8, (16 * n, 14, h, w), generator=torch.Generator().manual_seed(29)).float().cuda()
     sym = ent.fill(sym).contiguous()
     for name in ("PCONV_ENGINE_ROWS", "PCONV_ENGINE_ENCODE_INTERLEAVE", "PCONV_ENGINE_ENCODE_RANGES",
-                 "PCONV_ENGINE_STEPWISE_ENCODER", "PCONV_ENGINE_CHAIN", "PCONV_ENGINE_CU_MASK", "PCONV_EE_MFMA_FORM"):
+                 "PCONV_ENGINE_STEPWISE_ENCODER", "PCONV_ENGINE_CHAIN", "PCONV_ENGINE_CU_MASK", "PCONV_EE_MFMA_FORM",
+                 "PCONV_EE_FUSE_TABLES", "PCONV_EE_FUSE_PPW"):
         monkeypatch.delenv(name, raising=False)
     ref_engine = EntropyEngine(ent, h, w, n, "cuda:0")
     ref = ref_engine.encode(sym)
@@ -292,7 +293,11 @@ def test_engine_knobs_that_must_not_change_a_stream(hip_backend, monkeypatch):
                 {"PCONV_ENGINE_ENCODE_RANGES": "1"}, {"PCONV_ENGINE_ENCODE_RANGES": "7"},
                 {"PCONV_ENGINE_ROWS": "int32", "PCONV_ENGINE_CHAIN": "host"}, {"PCONV_ENGINE_CHAIN": "queued"},
                 {"PCONV_ENGINE_STEPWISE_ENCODER": "1"}, {"PCONV_ENGINE_CU_MASK": "0:64"},
-                {"PCONV_EE_MFMA_FORM": "16x4"}):
+                {"PCONV_EE_MFMA_FORM": "16x4"},
+                # (r6) the decoder's last layer + table kernel as one launch, on both chains
+                {"PCONV_EE_FUSE_TABLES": "1", "PCONV_ENGINE_CHAIN": "host"},
+                {"PCONV_EE_FUSE_TABLES": "1", "PCONV_ENGINE_CHAIN": "queued"},
+                {"PCONV_EE_FUSE_TABLES": "1", "PCONV_EE_FUSE_PPW": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         e = EntropyEngine(ent, h, w, n, "cuda:0")
