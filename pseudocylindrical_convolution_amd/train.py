@@ -153,10 +153,10 @@ def make_datasets(args):
 def Job(rank, world_size, args):
     """what one rank does (reference: trainDDP_Full.py:102-163)"""
     on_gpu = args.device == 'cuda'
-    cid = int(os.environ.get('LOCAL_RANK', rank)) if on_gpu else 0
+    cid = int(os.environ.get('LOCAL_RANK', rank)) if (on_gpu and not args.share_gpu) else 0
     args.gpu_id = cid
     torch.manual_seed(args.seed)  # same initial weights on every rank; DDP broadcasts rank 0's anyway
-    setup(rank, world_size, 'nccl' if on_gpu else 'gloo')
+    setup(rank, world_size, args.dist_backend or ('nccl' if on_gpu else 'gloo'))
     device = torch.device('cuda:%d' % cid) if on_gpu else torch.device('cpu')
     if on_gpu:
         torch.cuda.set_device(device)
@@ -237,6 +237,15 @@ def Job(rank, world_size, args):
         history.append((last, ls))
         if rank == 0:
             log.log(saver.save(model, ls))
+    if world_size > 1:
+        # the ranks end with the same parameters (DDP averaged every gradient): spread of a checksum over the ranks
+        chk = torch.zeros(1, dtype=torch.float64, device=device)
+        for p in model.module.parameters():
+            chk += p.detach().double().abs().sum()
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        log.log('parameter checksum over {} ranks: {:.9e}, spread {:.3e}'.format(world_size, hi.item(), (hi - lo).item()))
     dist.barrier()
     dist.destroy_process_group()
     return history
@@ -291,6 +300,11 @@ def build_parser():
     parser.add_argument('--width', type=int, default=1024)
     parser.add_argument('--workers', type=int, default=4)
     parser.add_argument('--max-steps', type=int, default=0, help='stop an epoch after this many batches (0: all)')
+    parser.add_argument('--dist-backend', default=None, choices=['nccl', 'gloo'],
+                        help='default: nccl (RCCL) on the GPU, gloo on the CPU.  gloo with --device cuda = several ranks on ONE '
+                             'GPU (RCCL refuses two ranks per device): a rehearsal of the DDP path, not a deployment')
+    parser.add_argument('--share-gpu', action='store_true', default=False,
+                        help='every rank on cuda:0 (with --dist-backend gloo): rehearsal on a one-GPU box')
     parser.add_argument('--seed', type=int, default=0)
     parser.add_argument('--verbose', action='store_true', default=False)
     return parser

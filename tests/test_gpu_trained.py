@@ -120,3 +120,21 @@ def test_trained_codec_equals_the_oracle(hip_backend, weights, tmp_path, H, W, m
                                "symbol_histogram": torch.bincount(csym.flatten().long(), minlength=8).tolist()})
     assert err < 1e-4, "reconstruction differs from the oracle by %g" % err
     assert psnr > 20.0, "a trained model reconstructs an image (viewport PSNR %.1f dB)" % psnr
+
+
+def test_trained_model_per_op_loops_write_the_engines_file(hip_backend, weights, tmp_path):
+    """the reference's op-by-op loops (pseudo_codec.py:97-114, 145-160) on the HIP per-op kernels and the native engine
+    write and read the same file with the TRAINED entropy model too (sharp, position-dependent CDFs instead of the
+    near-uniform ones of randn * 0.05 weights)"""
+    H, W = 512, 1024
+    x = frame(H, W, 7).cuda()
+    enc, dec = codec(weights)
+    a, b = str(tmp_path / "engine.bin"), str(tmp_path / "per_op.bin")
+    enc(x, a)
+    enc.forward_per_op(x, b)
+    with open(a, "rb") as f, open(b, "rb") as g:
+        fa, fb = f.read(), g.read()
+    assert fa == fb and len(fa) > 1000
+    ra = dec(a, H, W).clone()
+    rb = dec.forward_per_op(b, H, W)
+    assert torch.equal(ra, rb)
