@@ -301,6 +301,13 @@ int pconv_conv3x3_wino(const float *in, const float *packed_u, const float *bias
                        int tn, int cin, int h, int w, int cout, int act, const float *slope,
                        const int32_t *col_limit, int npart, const float *residual, int trim,
                        int d2w, const long long *views, void *stream);
+/* The same convolution with a 2-row x 128-column workgroup tile instead of 4 x 64 (csrc/wino_flat.hip): for launches of
+ * TWO output rows (the remainders of PCONV.tile_conv2d's row split); same arguments, same packed weights, same bits per
+ * output as pconv_conv3x3_wino. */
+int pconv_conv3x3_wino_flat(const float *in, const float *packed_u, const float *bias, float *out,
+                       int tn, int cin, int h, int w, int cout, int act, const float *slope,
+                       const int32_t *col_limit, int npart, const float *residual, int trim,
+                       int d2w, const long long *views, void *stream);
 
 /* The same layers by Winograd F(4x2, 3x3) (csrc/wino42.hip): F(4, 3) vertically, F(2, 3) horizontally --
  * 3 instead of 4 (direct: 9) multiply-adds per input channel, output channel and pixel.  Same arguments and

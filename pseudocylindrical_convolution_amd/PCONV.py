@@ -1130,6 +1130,7 @@ def packed_wino_weight(owner, weight, stream):
 
 CONV3X3_DEFAULT = "wino42"
 WINO_ROW_SPLIT = os.environ.get("PCONV_WINO_SPLIT", "1") == "1"
+WINO_FLAT_REMAINDER = os.environ.get("PCONV_WINO_FLAT", "1") == "1"   # 2-row launches on csrc/wino_flat.hip (0: the 4-row tile)
 
 
 def conv3x3_mode():
@@ -1367,7 +1368,9 @@ def tile_conv2d(owner, x, weight, bias, stride, slope=None, col_limit=None, npar
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(x.device))
         views = _views(xv, ov, rv)
-        call("pconv_conv3x3_wino42" if use42 else "pconv_conv3x3_wino", _ptr(xv),
+        # a launch of exactly two output rows (the split's remainder) takes the 2 x 128-pixel workgroup tile
+        entry = "pconv_conv3x3_wino42" if use42 else ("pconv_conv3x3_wino_flat" if (rows == 2 and WINO_FLAT_REMAINDER) else "pconv_conv3x3_wino")
+        call(entry, _ptr(xv),
              _ptr(packed_wino42_weight(owner, weight, stream) if use42 else packed_wino_weight(owner, weight, stream)),
              _ptr(bias.detach()) if bias is not None else None, _ptr(ov), tn, cin, rows + 2, w, cout,
              1 if slope is not None else 0, _ptr(slope.detach()) if slope is not None else None, _ptr(col_limit),

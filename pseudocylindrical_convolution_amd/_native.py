@@ -64,6 +64,7 @@ _HIP_SIGNATURES = {
     "pconv_wino_pack_weight": [P, P, I, I, P],
     "pconv_wino_supported": [I, I, I, I, I],
     "pconv_conv3x3_wino": [P, P, P, P, I, I, I, I, I, I, P, P, I, P, I, I, P, P],
+    "pconv_conv3x3_wino_flat": [P, P, P, P, I, I, I, I, I, I, P, P, I, P, I, I, P, P],
     "pconv_wino42_packed_size": [I, I],
     "pconv_wino42_pack_weight": [P, P, I, I, P],
     "pconv_wino42_supported": [I, I, I, I, I],

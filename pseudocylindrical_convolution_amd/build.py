@@ -29,6 +29,7 @@ HIP_SOURCES = [
     "entropy_mfma.hip",
     "conv.hip",
     "wino.hip",
+    "wino_flat.hip",   # wino.hip again with a 2-row x 128-column workgroup tile (the row split's remainders)
     "wino42.hip",
     "backward.hip",
     "engine.cpp",
@@ -47,6 +48,7 @@ HIP_FLAGS = [
 ]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I" + INCLUDE]
 FILE_FLAGS = {}  # per-file additions to HIP_FLAGS (none at present)
+INCLUDES = {"wino_flat.hip": ["wino.hip"]}  # sources that #include another source: rebuilt when it changes
 
 
 def hipcc():
@@ -90,7 +92,8 @@ def _compile(src, flags, cc, hdr_time, as_hip):
     objdir = os.path.join(OBJ, "hip" if as_hip else "cxx")
     os.makedirs(objdir, exist_ok=True)
     obj = os.path.join(objdir, src + ".o")
-    if _stale(obj, max(os.path.getmtime(path), hdr_time)):
+    dep_time = max([os.path.getmtime(path)] + [os.path.getmtime(os.path.join(CSRC, d)) for d in INCLUDES.get(src, [])])
+    if _stale(obj, max(dep_time, hdr_time)):
         cmd = [cc] + flags + (FILE_FLAGS.get(src, []) if as_hip else [])
         if as_hip and src.endswith(".cpp"):
             cmd += ["-x", "hip"]

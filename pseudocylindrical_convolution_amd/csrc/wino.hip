@@ -69,8 +69,15 @@ typedef const __attribute__((address_space(1))) char glb_bytes_t;
 
 constexpr int kThreads = 512, kWaves = 8;
 constexpr int XW = 2;                                // GEMMs (xi) per wave
+#ifdef PCONV_WINO_FLAT
+// (r6) second build of this file (wino_flat.hip): one tile row of 64 tiles = 2 x 128 output pixels per workgroup, for
+// the 2-row REMAINDERS of the row split (PCONV.tile_conv2d): the 4-row workgroup ran them half empty
+constexpr int TX = 64, TY = 1;
+#else
 constexpr int TX = 32, TY = 2;                       // Winograd tiles of a workgroup
-constexpr int OROWS = 2 * TY, OCOLS = 2 * TX;        // 4 x 64 output pixels
+#endif
+constexpr bool kFlat = TY == 1;
+constexpr int OROWS = 2 * TY, OCOLS = 2 * TX;        // 4 x 64 output pixels (flat: 2 x 128)
 constexpr int CO = 96;                               // couts of a workgroup
 constexpr int KC = 4;                                // input channels per stage (patch, V, weights)
 constexpr int PR = OROWS + 2, PC = OCOLS + 2;        // 6 x 66 patch
@@ -91,7 +98,7 @@ static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS of a CU");
 static_assert(PSZ <= PBUF && PBUF % 2 == 0, "patch buffer");
 static_assert(USZ % 256 == 0, "weight stage = whole 16-byte DMA instructions");
 static_assert(PLD + 2 * ULD < 64, "vmcnt counts to 63");
-static_assert(PLD <= 4 && ULD <= 4, "DMA pieces of a chunk fit the gaps of one step of the matrix block");
+static_assert(PLD <= 5 && ULD <= 4, "DMA pieces of a chunk fit the gaps of the matrix block (a fifth patch piece: step 1)");
 static_assert(URING == 4 && PRING == 2, "the main loop is unrolled over four chunks: ring slots are compile-time");
 static_assert(XW == 2, "the way out stores a wave's two GEMMs by hand");
 static_assert(KC == 4 && kWaves * XW == 16, "transform: waves 0-3 take one channel of the stage each; two GEMMs per wave");
@@ -247,6 +254,11 @@ __device__ __forceinline__ void wino_mma_steps(f32x16 (&acc)[XW][3][2], float (&
     if constexpr (IL && ST == 0 && J < PLD) {
       __builtin_amdgcn_sched_barrier(0);
       pd(j_c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (IL && ST == 1 && J == 0 && PLD > 4) {  // (flat build: 2080 patch elements, a fifth piece)
+      __builtin_amdgcn_sched_barrier(0);
+      pd(std::integral_constant<int, 4>{});
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (IL && ST == NST - 1 && J < ULD) {
@@ -416,7 +428,8 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   // transform_full is the same arithmetic for a whole pair, in one piece: stage 0, by waves 0-3.
   const int wave4 = wave >> 2, tch = wave & 3;  // (uniform)
   const int tty = lane >> 5, ttx = lane & 31;
-  const float *tp0 = Ps + (tch * PR + 2 * tty) * PC + 2 * ttx;  // the pair's 4 x 4 block in patch stage 0
+  const float *tp0 = kFlat ? Ps + tch * PR * PC + 2 * lane       // (flat: one tile row, tile = lane)
+                           : Ps + (tch * PR + 2 * tty) * PC + 2 * ttx;  // the pair's 4 x 4 block in patch stage 0
   float *tv0 = Vs + tch * (TX * TY) + lane;                     // its slot in V buffer 0
   const WinoHalf half_t = {tp0, tv0 + wave4 * 8 * (KC * TX * TY), wave4 ? 2 * PC : 0, wave4 ? PC : 2 * PC,
                            wave4 ? 3 * PC : 2 * PC, wave4 ? -1.f : 1.f};
@@ -567,7 +580,9 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
   const int act = ep.act;
   const int trim_at = ep.trim ? limit : wo;
   const float *resp = RES ? ep.residual + (size_t)t * ep.vres.ts : nullptr;
-  const int ocol = c0 + 2 * ecol;
+  // accumulator half n of a wave = tile row n (4-row workgroup) or tile columns 32 n .. 32 n + 31 (flat)
+  auto ocol_of = [&](int n) { return kFlat ? c0 + 2 * (32 * n + ecol) : c0 + 2 * ecol; };
+  auto orow_of = [&](int n) { return kFlat ? r0 : r0 + 2 * n; };
   // residual values of round k = (m, n): requested two rounds ahead (a round is ~1 us, a load from HBM
   // under load 2-3 us: requested at the head of their own round every one of the six waits was exposed)
   struct ResPair {
@@ -581,14 +596,14 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
     ResPair rp = {{{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}}};
     if (RES && round < 6) {
       const int m = round >> 1, n = round & 1;
-      const int oc = ocol < wo ? ocol : wo - 2;
+      const int oc = ocol_of(n) < wo ? ocol_of(n) : wo - 2;
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         int co = cout0 + m * 32 + erow + 16 * j;
         co = co < cout ? co : cout - 1;
 #pragma unroll
         for (int a2 = 0; a2 < 2; a2++) {
-          int rr = r0 + 2 * n + a2;
+          int rr = orow_of(n) + a2;
           rr = rr < ho ? rr : ho - 1;
           rp.v[j][a2] = *reinterpret_cast<const f32x2 *>(resp + (size_t)co * ep.vres.cs + (size_t)rr * ep.vres.rs + oc);
         }
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(kThreads) void wino_conv3x3_kernel(
 #pragma unroll
     for (int n = 0; n < 2; n++) {
       float *Es = lds + ((m * 2 + n) & 1) * ESZ;  // [xi][32 couts][32 tiles]
-      const int orow = r0 + 2 * n;
+      const int orow = orow_of(n), ocol = ocol_of(n);
       const ResPair rcur = rq[(m * 2 + n) & 1];
       rq[(m * 2 + n) & 1] = load_res(m * 2 + n + 2);
       // Es[xi][r][lane]: accumulator register r of lane (half, l31) = cout row (r & 3) + 8 (r >> 2) + 4 half
@@ -703,6 +718,7 @@ inline bool view_ok(const WView &v, int c, int h, int w) {
 
 }  // namespace
 
+#ifndef PCONV_WINO_FLAT
 #ifdef PCONV_WINO_STAMP
 extern "C" int pconv_wino_read_stamps(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(wino_stamps), sizeof(wino_stamps)) == hipSuccess ? 0 : 1;
@@ -733,10 +749,15 @@ extern "C" int pconv_wino_supported(int cin, int h, int w, int cout, int d2w) {
   return 1;
 }
 
-extern "C" int pconv_conv3x3_wino(const float *in, const float *packed_u, const float *bias, float *out, int tn, int cin,
-                                  int h, int w, int cout, int act, const float *slope, const int32_t *col_limit,
-                                  int npart, const float *residual, int trim, int d2w, const long long *views,
-                                  void *stream) {
+#define PCONV_WINO_ENTRY pconv_conv3x3_wino
+#else   // the flat build exports its convolution only; weights are packed by the 4-row build (same layout)
+#define PCONV_WINO_ENTRY pconv_conv3x3_wino_flat
+#endif
+
+extern "C" int PCONV_WINO_ENTRY(const float *in, const float *packed_u, const float *bias, float *out, int tn, int cin,
+                                int h, int w, int cout, int act, const float *slope, const int32_t *col_limit,
+                                int npart, const float *residual, int trim, int d2w, const long long *views,
+                                void *stream) {
   PCONV_REQUIRE(in && packed_u && out, "conv3x3_wino: null pointer");
   PCONV_REQUIRE(pconv_wino_supported(cin, h, w, cout, d2w), "conv3x3_wino: unsupported shape %d x %d x %d -> %d", cin, h, w,
                 cout);

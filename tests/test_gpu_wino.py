@@ -182,3 +182,38 @@ def test_wino_fallbacks_are_counted(hip_backend, monkeypatch):
     assert len(P().conv_fallbacks) == 1
     assert P()._native.hip_lib().pconv_wino_supported(8, 6, 66, 96, 0) == 0      # the header's contract: cin % 16
     assert P()._native.hip_lib().pconv_wino_supported(16, 6, 66, 32, 0) == 1
+
+
+@pytest.mark.parametrize("cfg", [(16, 192, 4, 262, 192), (3, 96, 4, 70, 96), (32, 192, 4, 1030, 192), (2, 48, 4, 130, 64)])
+def test_two_row_launches_take_the_flat_tile_and_write_the_same_bits(cfg, hip_backend, monkeypatch):
+    """(r6) csrc/wino_flat.hip = wino.hip compiled with a 2-row x 128-column workgroup tile, for launches of exactly two
+    output rows (the remainders of the row split): the same operations per output in the same order, so the SAME BITS as
+    the 4 x 64 tile -- plain, residual + trim + PReLU with column limits, inside padded buffers, and the Dtow store"""
+    tn, cin, h, w, cout = cfg
+    x, wt, b, sl = data(*cfg, seed=31)
+    ho, wo = h - 2, w - 2
+    assert ho == 2
+    res = torch.randn(tn, cout, ho, wo, generator=torch.Generator().manual_seed(32))
+    limit = torch.tensor([wo, 40, 64, 3, 65, 128, wo - 1, 1] * 2, dtype=torch.int32).to(DEV)
+
+    def inside(t, p):
+        buf = torch.full((t.shape[0], t.shape[1], t.shape[2] + 2 * p, t.shape[3] + 2 * p), 7.0, device=DEV)
+        buf[:, :, p:-p, p:-p] = t.to(DEV)
+        return buf[:, :, p:-p, p:-p]
+
+    def run(flat, xin, **kw):
+        monkeypatch.setattr(P(), "WINO_FLAT_REMAINDER", flat)
+        return conv(monkeypatch, "wino", xin, wt.to(DEV), b.to(DEV), 1, **kw)
+
+    ref64 = torch.nn.functional.conv2d(x.double(), wt.double(), b.double())
+    a, f = run(False, x.to(DEV)), run(True, x.to(DEV))
+    assert torch.equal(a, f) and (f.cpu().double() - ref64).abs().max().item() < 2e-5
+    for (xin, rin, ring) in ((x.to(DEV), res.to(DEV), 0), (inside(x, 2), inside(res, 2), 2)):
+        kw = dict(slope=sl.to(DEV), col_limit=limit, npart=16, residual=rin, trim=True, ring=ring)
+        a, f = run(False, xin, **kw), run(True, xin, **kw)
+        assert torch.equal(a, f)
+        d = conv(monkeypatch, "direct", xin, wt.to(DEV), b.to(DEV), 1, **kw)
+        assert (f - d).abs().max().item() < 2e-5
+    if cout % 4 == 0:
+        a, f = run(False, x.to(DEV), slope=sl.to(DEV), d2w=True), run(True, x.to(DEV), slope=sl.to(DEV), d2w=True)
+        assert a.shape == (tn, cout // 4, 2 * ho, 2 * wo) and torch.equal(a, f)
